@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build libarx_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+OUT=../libarx_hip.so
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -ffp-contract=fast"
+mkdir -p ../_build
+pids=()
+for f in runtime encoder search; do
+  hipcc $FLAGS -c $f.hip -o ../_build/$f.o ${ARX_HIPCC_EXTRA} &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../_build/runtime.o ../_build/encoder.o ../_build/search.o
+echo "built $(realpath $OUT)"

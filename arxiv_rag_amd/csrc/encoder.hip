@@ -1,0 +1,317 @@
+// arx_encoder_*: host side of the encoder forward (C ABI in include/arx.h).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "arx_common.h"
+#include "encoder_kernels.h"
+#include "gemm.h"
+
+// MPNet / T5 bidirectional bucket (TF modeling_mpnet.py:330-349). rel = key_pos - query_pos.
+// Integer-exact restatement: the float32 expression there lands on the expected side of every
+// boundary (n = 16, 32, 64 are exact powers); the +1e-6 reproduces that (golden: mpnet_tables.npz).
+extern "C" int32_t arx_mpnet_bucket(int32_t rel, int32_t num_buckets, int32_t max_distance) {
+    int n = -rel;
+    const int nb = num_buckets / 2;
+    int ret = 0;
+    if (n < 0) { ret = nb; n = -n; }
+    const int max_exact = nb / 2;
+    if (n < max_exact) return ret + n;
+    int v = max_exact + (int)floor(log((double)n / max_exact) / log((double)max_distance / max_exact) * (nb - max_exact) + 1e-6);
+    if (v > nb - 1) v = nb - 1;
+    return ret + v;
+}
+
+// ---- handle -----------------------------------------------------------------------------------
+struct arx_encoder {
+    arx_encoder_config cfg;
+    arx_encoder_weights w;
+    std::vector<arx_layer_weights> layers;
+    int max_tokens, max_seqs, tok_pad;
+    char* ws = nullptr;
+    int64_t ws_bytes = 0;
+    int32_t* cu = nullptr;
+    uint16_t *x = nullptr, *x1 = nullptr, *qkv = nullptr, *ctx = nullptr, *y = nullptr, *hbuf = nullptr;
+    float* bias_tbl = nullptr;
+    uint16_t* tap = nullptr;
+    int tap_layer = -1;
+    bool glds = true;
+};
+
+struct WsLayout {
+    int64_t cu, x, x1, qkv, ctx, y, hbuf, bias, total;
+};
+static WsLayout ws_layout(const arx_encoder_config& c, int max_tokens, int max_seqs) {
+    const int64_t tp = round_up64(max_tokens, 256);
+    WsLayout l;
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { int64_t r = o; o += round_up64(bytes, 256); return r; };
+    l.cu = take((int64_t)(max_seqs + 1) * 4);
+    l.x = take(tp * c.hidden * 2);
+    l.x1 = take(tp * c.hidden * 2);
+    l.qkv = take(tp * c.hidden * 3 * 2);
+    l.ctx = take(tp * c.hidden * 2);
+    l.y = take(tp * c.hidden * 2);
+    l.hbuf = take(tp * c.ffn * 2);
+    l.bias = take((int64_t)c.heads * ARX_BIAS_ROW * 4);
+    l.total = o;
+    return l;
+}
+
+static int check_cfg(const arx_encoder_config* c) {
+    ARX_REQUIRE(c != nullptr, "cfg is null");
+    ARX_REQUIRE(c->arch == ARX_ARCH_MPNET || c->arch == ARX_ARCH_BERT, "unknown arch %d", c->arch);
+    ARX_REQUIRE(c->hidden > 0 && c->hidden % 64 == 0 && c->hidden <= 1024, "hidden=%d must be a multiple of 64, <= 1024", c->hidden);
+    ARX_REQUIRE(c->heads > 0 && c->hidden % c->heads == 0, "hidden %% heads != 0");
+    const int dh = c->hidden / c->heads;
+    ARX_REQUIRE(dh == 32 || dh == 64, "head_dim=%d unsupported (32 or 64)", dh);
+    ARX_REQUIRE(c->ffn > 0 && c->ffn % 64 == 0, "ffn=%d must be a multiple of 64", c->ffn);
+    ARX_REQUIRE(c->layers > 0 && c->vocab_size > 0 && c->max_pos > 0, "bad layers/vocab/max_pos");
+    ARX_REQUIRE(c->pool == ARX_POOL_MEAN || c->pool == ARX_POOL_CLS, "unknown pool %d", c->pool);
+    return ARX_OK;
+}
+
+extern "C" int64_t arx_encoder_workspace_bytes(const arx_encoder_config* cfg, int32_t max_tokens, int32_t max_seqs) {
+    if (check_cfg(cfg) != ARX_OK || max_tokens <= 0 || max_seqs <= 0) return -1;
+    return ws_layout(*cfg, max_tokens, max_seqs).total;
+}
+
+extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_encoder_weights* w, int32_t max_tokens,
+                                      int32_t max_seqs, arx_encoder** out) {
+    int rc = check_cfg(cfg);
+    if (rc != ARX_OK) return rc;
+    ARX_REQUIRE(w && out, "null weights/out");
+    ARX_REQUIRE(max_tokens > 0 && max_seqs > 0, "max_tokens/max_seqs must be positive");
+    ARX_REQUIRE(w->word_emb && w->pos_emb && w->emb_ln_g && w->emb_ln_b && w->layers, "missing embedding weights");
+    ARX_REQUIRE(cfg->arch != ARX_ARCH_BERT || w->type_emb, "BERT needs type_emb");
+    ARX_REQUIRE(cfg->arch != ARX_ARCH_MPNET || w->rel_bias, "MPNet needs rel_bias");
+    for (int i = 0; i < cfg->layers; ++i) {
+        const arx_layer_weights& L = w->layers[i];
+        ARX_REQUIRE(L.w_qkv && L.b_qkv && L.w_o && L.b_o && L.ln1_g && L.ln1_b && L.w_fc1 && L.b_fc1 && L.w_fc2 &&
+                        L.b_fc2 && L.ln2_g && L.ln2_b, "layer %d: missing weights", i);
+    }
+    arx_encoder* h = new arx_encoder();
+    h->cfg = *cfg;
+    h->w = *w;
+    h->layers.assign(w->layers, w->layers + cfg->layers);
+    h->w.layers = h->layers.data();
+    h->max_tokens = max_tokens;
+    h->max_seqs = max_seqs;
+    h->tok_pad = (int)round_up64(max_tokens, 256);
+    const char* e = getenv("ARX_GEMM_GLDS");
+    h->glds = !(e && e[0] == '0');
+    const WsLayout l = ws_layout(*cfg, max_tokens, max_seqs);
+    hipError_t he = hipMalloc((void**)&h->ws, l.total);
+    if (he != hipSuccess) {
+        arx_set_error("hipMalloc(%lld bytes workspace): %s", (long long)l.total, hipGetErrorString(he));
+        delete h;
+        return ARX_ERR_HIP;
+    }
+    h->ws_bytes = l.total;
+    // padded rows are read by GEMM tiles (results discarded): keep them finite
+    (void)hipMemset(h->ws, 0, l.total);
+    h->cu = (int32_t*)(h->ws + l.cu);
+    h->x = (uint16_t*)(h->ws + l.x);
+    h->x1 = (uint16_t*)(h->ws + l.x1);
+    h->qkv = (uint16_t*)(h->ws + l.qkv);
+    h->ctx = (uint16_t*)(h->ws + l.ctx);
+    h->y = (uint16_t*)(h->ws + l.y);
+    h->hbuf = (uint16_t*)(h->ws + l.hbuf);
+    h->bias_tbl = (float*)(h->ws + l.bias);
+    if (cfg->arch == ARX_ARCH_MPNET) {
+        // Toeplitz bias rows, pre-multiplied by log2(e): tbl[h][d + C] = rel_bias[bucket(d)][h] * log2e
+        std::vector<float> rb((size_t)cfg->rel_buckets * cfg->heads);
+        he = hipMemcpy(rb.data(), w->rel_bias, rb.size() * 4, hipMemcpyDeviceToHost);
+        if (he != hipSuccess) {
+            arx_set_error("copy rel_bias: %s", hipGetErrorString(he));
+            (void)hipFree(h->ws);
+            delete h;
+            return ARX_ERR_HIP;
+        }
+        std::vector<float> tbl((size_t)cfg->heads * ARX_BIAS_ROW);
+        const float log2e = 1.4426950408889634f;
+        for (int d = -ARX_BIAS_CENTER; d <= ARX_BIAS_CENTER; ++d) {
+            const int bk = arx_mpnet_bucket(d, cfg->rel_buckets, cfg->rel_max_distance);
+            for (int hd = 0; hd < cfg->heads; ++hd)
+                tbl[(size_t)hd * ARX_BIAS_ROW + d + ARX_BIAS_CENTER] = rb[(size_t)bk * cfg->heads + hd] * log2e;
+        }
+        he = hipMemcpy(h->bias_tbl, tbl.data(), tbl.size() * 4, hipMemcpyHostToDevice);
+        if (he != hipSuccess) {
+            arx_set_error("upload bias table: %s", hipGetErrorString(he));
+            (void)hipFree(h->ws);
+            delete h;
+            return ARX_ERR_HIP;
+        }
+    }
+    *out = h;
+    return ARX_OK;
+}
+
+extern "C" void arx_encoder_destroy(arx_encoder* h) {
+    if (!h) return;
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->tap) (void)hipFree(h->tap);
+    delete h;
+}
+
+extern "C" int32_t arx_encoder_set_tap(arx_encoder* h, int32_t layer) {
+    ARX_REQUIRE(h, "null handle");
+    ARX_REQUIRE(layer >= -1 && layer <= h->cfg.layers, "tap layer out of range");
+    if (layer >= 0 && !h->tap) ARX_HIP_CHECK(hipMalloc((void**)&h->tap, (int64_t)h->tok_pad * h->cfg.hidden * 2));
+    h->tap_layer = layer;
+    return ARX_OK;
+}
+
+extern "C" int32_t arx_encoder_debug_hidden(arx_encoder* h, int32_t /*layer_slot*/, float* dst, int32_t n_tokens, void* stream) {
+    ARX_REQUIRE(h && h->tap && dst, "no tap recorded");
+    ARX_REQUIRE(n_tokens > 0 && n_tokens <= h->max_tokens, "n_tokens out of range");
+    const int64_t n = (int64_t)n_tokens * h->cfg.hidden;
+    bf16_to_f32_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(h->tap, dst, n);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
+// ---- GEMM dispatch ------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool GLDS, int MODE>
+static int launch_gemm_cfg(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int N, int K,
+                           const EpiParams& ep, hipStream_t st) {
+    using ML = GemmMainloop<bf16_t, BM, BN, WM, WN, GLDS>;
+    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, GLDS, MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ML::SMEM_BYTES));
+        attr_set = true;
+    }
+    const int tm = cdiv(M, BM), tn = cdiv(N, BN);
+    kern<<<tm * tn, ML::NT, ML::SMEM_BYTES, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
+template <int MODE>
+static int launch_gemm(int cls, bool glds, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int N, int K,
+                       const EpiParams& ep, hipStream_t st) {
+    if (K % 64 != 0 || N % 4 != 0) {
+        arx_set_error("gemm: K=%d must be a multiple of 64 and N=%d of 4", K, N);
+        return ARX_ERR_ARG;
+    }
+    const bool wide = (N % 256 == 0);
+    ProfScope ps(cls, st);
+    if (glds) {
+        return wide ? launch_gemm_cfg<256, 256, 2, 4, true, MODE>(A, lda, W, ldw, M, N, K, ep, st)
+                    : launch_gemm_cfg<256, 128, 4, 2, true, MODE>(A, lda, W, ldw, M, N, K, ep, st);
+    }
+    return wide ? launch_gemm_cfg<256, 256, 2, 4, false, MODE>(A, lda, W, ldw, M, N, K, ep, st)
+                : launch_gemm_cfg<256, 128, 4, 2, false, MODE>(A, lda, W, ldw, M, N, K, ep, st);
+}
+
+// ---- attention dispatch -------------------------------------------------------------------------
+template <int DH, bool HB, int NW>
+static int launch_attn_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
+    auto kern = attention_kernel<DH, HB, NW>;
+    const int Lk = (max_len + 31) & ~31;
+    const int smem = AttnSmem<DH>::total(Lk, HB);
+    static int attr_max = 0;
+    if (smem > attr_max) {
+        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_max = smem;
+    }
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
+    dim3 grid(cdiv(max_len, 32 * NW), h->cfg.heads, n_seqs);
+    ProfScope ps(ARX_K_ATTENTION, st);
+    kern<<<grid, NW * 64, smem, st>>>(h->qkv, h->ctx, h->cu, h->bias_tbl, h->cfg.hidden, scale_log2e);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
+static int launch_attn(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
+    const int dh = h->cfg.hidden / h->cfg.heads;
+    const bool hb = h->cfg.arch == ARX_ARCH_MPNET;
+    const bool big = max_len > 256;     // > 80 KB of LDS per block anyway: use 8 waves per block
+    if (dh == 64) {
+        if (hb) return big ? launch_attn_cfg<64, true, 8>(h, n_seqs, max_len, st) : launch_attn_cfg<64, true, 4>(h, n_seqs, max_len, st);
+        return big ? launch_attn_cfg<64, false, 8>(h, n_seqs, max_len, st) : launch_attn_cfg<64, false, 4>(h, n_seqs, max_len, st);
+    }
+    if (hb) return big ? launch_attn_cfg<32, true, 8>(h, n_seqs, max_len, st) : launch_attn_cfg<32, true, 4>(h, n_seqs, max_len, st);
+    return big ? launch_attn_cfg<32, false, 8>(h, n_seqs, max_len, st) : launch_attn_cfg<32, false, 4>(h, n_seqs, max_len, st);
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32_t seq_stride, const int32_t* lens,
+                                       int32_t n_seqs, int32_t max_len, int32_t total_tokens, float* out_f32,
+                                       int64_t out_stride, void* out_f16, int64_t out16_stride, int32_t normalize,
+                                       void* stream) {
+    ARX_REQUIRE(h && ids && lens, "null handle/ids/lens");
+    ARX_REQUIRE(out_f32 || out_f16, "no output buffer");
+    ARX_REQUIRE(n_seqs > 0 && max_len > 0 && max_len <= 512, "n_seqs=%d max_len=%d (max_len must be in 1..512)", n_seqs, max_len);
+    ARX_REQUIRE(seq_stride >= max_len, "seq_stride < max_len");
+    ARX_REQUIRE(total_tokens > 0 && (int64_t)total_tokens <= (int64_t)n_seqs * max_len, "total_tokens out of range");
+    if (n_seqs > h->max_seqs || total_tokens > h->max_tokens) {
+        arx_set_error("batch (%d seqs, %d tokens) exceeds handle capacity (%d, %d)", n_seqs, total_tokens, h->max_seqs, h->max_tokens);
+        return ARX_ERR_CAPACITY;
+    }
+    ARX_REQUIRE(!out_f32 || out_stride >= h->cfg.hidden, "out_stride < hidden");
+    ARX_REQUIRE(!out_f16 || out16_stride >= h->cfg.hidden, "out16_stride < hidden");
+    hipStream_t st = (hipStream_t)stream;
+    const arx_encoder_config& c = h->cfg;
+    const int H = c.hidden, F = c.ffn, T = total_tokens;
+    int rc;
+
+    scan_lens_kernel<<<1, 256, 0, st>>>(lens, h->cu, n_seqs);
+    ARX_HIP_CHECK(hipGetLastError());
+    {
+        ProfScope ps(ARX_K_EMBED, st);
+        dim3 grid(cdiv(max_len, 4), n_seqs);
+        if (c.arch == ARX_ARCH_MPNET)
+            embed_ln_kernel<ARX_ARCH_MPNET><<<grid, 256, 0, st>>>(ids, seq_stride, lens, h->cu, h->w.word_emb, h->w.pos_emb, nullptr,
+                                                                  h->w.emb_ln_g, h->w.emb_ln_b, h->x, H, c.vocab_size, c.max_pos, c.pad_id, c.ln_eps);
+        else
+            embed_ln_kernel<ARX_ARCH_BERT><<<grid, 256, 0, st>>>(ids, seq_stride, lens, h->cu, h->w.word_emb, h->w.pos_emb, h->w.type_emb,
+                                                                 h->w.emb_ln_g, h->w.emb_ln_b, h->x, H, c.vocab_size, c.max_pos, c.pad_id, c.ln_eps);
+        ARX_HIP_CHECK(hipGetLastError());
+    }
+    auto tap = [&](int layer) -> int {
+        if (h->tap_layer == layer && h->tap) ARX_HIP_CHECK(hipMemcpyAsync(h->tap, h->x, (int64_t)T * H * 2, hipMemcpyDeviceToDevice, st));
+        return ARX_OK;
+    };
+    if ((rc = tap(0)) != ARX_OK) return rc;
+
+    const int ln_grid = cdiv(T, 4);
+    for (int li = 0; li < c.layers; ++li) {
+        const arx_layer_weights& L = h->layers[li];
+        EpiParams ep;
+        // qkv = x Wqkv^T + b
+        ep = EpiParams{h->qkv, 3 * (int64_t)H, L.b_qkv, nullptr, 0};
+        if ((rc = launch_gemm<EPI_BIAS>(ARX_K_GEMM_QKV, h->glds, h->x, H, (const uint16_t*)L.w_qkv, H, T, 3 * H, H, ep, st)) != ARX_OK) return rc;
+        if ((rc = launch_attn(h, n_seqs, max_len, st)) != ARX_OK) return rc;
+        // y = ctx Wo^T + b + x ; x1 = LN(y)
+        ep = EpiParams{h->y, H, L.b_o, h->x, H};
+        if ((rc = launch_gemm<EPI_BIAS_RESID>(ARX_K_GEMM_OPROJ, h->glds, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st)) != ARX_OK) return rc;
+        { ProfScope ps(ARX_K_LAYERNORM, st);
+        layernorm_kernel<<<ln_grid, 256, 0, st>>>(h->y, h->x1, L.ln1_g, L.ln1_b, h->cu + n_seqs, H, c.ln_eps); }
+        ARX_HIP_CHECK(hipGetLastError());
+        // hbuf = gelu(x1 W1^T + b1) ; y = hbuf W2^T + b2 + x1 ; x = LN(y)
+        ep = EpiParams{h->hbuf, F, L.b_fc1, nullptr, 0};
+        if ((rc = launch_gemm<EPI_BIAS_GELU>(ARX_K_GEMM_FC1, h->glds, h->x1, H, (const uint16_t*)L.w_fc1, H, T, F, H, ep, st)) != ARX_OK) return rc;
+        ep = EpiParams{h->y, H, L.b_fc2, h->x1, H};
+        if ((rc = launch_gemm<EPI_BIAS_RESID>(ARX_K_GEMM_FC2, h->glds, h->hbuf, F, (const uint16_t*)L.w_fc2, F, T, H, F, ep, st)) != ARX_OK) return rc;
+        { ProfScope ps(ARX_K_LAYERNORM, st);
+        layernorm_kernel<<<ln_grid, 256, 0, st>>>(h->y, h->x, L.ln2_g, L.ln2_b, h->cu + n_seqs, H, c.ln_eps); }
+        ARX_HIP_CHECK(hipGetLastError());
+        if ((rc = tap(li + 1)) != ARX_OK) return rc;
+    }
+    ProfScope pps(ARX_K_POOL, st);
+    pool_norm_kernel<<<n_seqs, 256, 0, st>>>(h->x, h->cu, H, c.pool, normalize, out_f32, out_stride, (f16_t*)out_f16, out16_stride);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
+extern "C" int32_t arx_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    ARX_REQUIRE(src && dst && n >= 0, "bad args");
+    if (n == 0) return ARX_OK;
+    f32_to_bf16_kernel<<<cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(src, (uint16_t*)dst, n);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}

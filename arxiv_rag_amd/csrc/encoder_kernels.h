@@ -1,0 +1,415 @@
+// Non-GEMM encoder kernels: position ids + packing offsets, embedding gather + LayerNorm, row LayerNorm,
+// fused attention (S <= 512, whole K/V of one (sequence, head) resident in LDS), masked mean / CLS pool
+// + L2 normalise.  Activations are token-PACKED: row t of every [T, *] buffer is token (t - cu[b]) of
+// sequence b, no padding rows between sequences.
+#pragma once
+#include "arx_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// cu[b] = sum_{i<b} lens[i]  (one block; n_seqs <= a few thousand)
+__global__ void scan_lens_kernel(const int32_t* __restrict__ lens, int32_t* __restrict__ cu, int n) {
+    __shared__ int32_t part[1024];
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int per = (n + nt - 1) / nt;
+    const int b0 = tid * per, b1 = min(n, b0 + per);
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += lens[b];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < nt; ++i) { int v = part[i]; part[i] = run; run += v; }
+        cu[n] = run;
+    }
+    __syncthreads();
+    int run = part[tid];
+    for (int b = b0; b < b1; ++b) { cu[b] = run; run += lens[b]; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Embedding gather + LayerNorm -> bf16 x[T,H].  One wave per token; grid (ceil(max_len/4), n_seqs), 256 thr.
+// MPNet position id = cumsum(ids != pad)[s] * (ids[s] != pad) + pad  (TF modeling_mpnet.py:873-881);
+// BERT position id = s, plus token-type row 0.
+template <int ARCH>
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int32_t* __restrict__ ids, int seq_stride,
+                                                        const int32_t* __restrict__ lens, const int32_t* __restrict__ cu,
+                                                        const float* __restrict__ word, const float* __restrict__ pos,
+                                                        const float* __restrict__ type0, const float* __restrict__ g,
+                                                        const float* __restrict__ bta, uint16_t* __restrict__ x,
+                                                        int H, int vocab, int max_pos, int pad_id, float eps) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int s = blockIdx.x * 4 + w;
+    const int L = lens[b];
+    if (s >= L) return;
+    const int32_t* row = ids + (int64_t)b * seq_stride;
+    int id = row[s];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int pid;
+    if (ARCH == ARX_ARCH_MPNET) {
+        int cnt = 0;                                   // non-pad tokens in [0, s]
+        for (int c0 = 0; c0 <= s; c0 += 64) {
+            const int i = c0 + lane;
+            const bool np = (i <= s) && (row[i] != pad_id);
+            cnt += __popcll(__ballot(np));
+        }
+        pid = (row[s] != pad_id) ? cnt + pad_id : pad_id;
+    } else {
+        pid = s;
+    }
+    pid = pid >= max_pos ? max_pos - 1 : pid;
+    const float* wr = word + (int64_t)id * H;
+    const float* pr = pos + (int64_t)pid * H;
+    // H <= 1024: each lane holds up to 4 float4 chunks (chunk c covers columns 4*(lane + 64*c) ..)
+    f32x4 v[4];
+    float sum = 0.f;
+    const int nch = H >> 2;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            f32x4 a = *reinterpret_cast<const f32x4*>(wr + ch * 4);
+            const f32x4 p4 = *reinterpret_cast<const f32x4*>(pr + ch * 4);
+            a += p4;
+            if (ARCH == ARX_ARCH_BERT) a += *reinterpret_cast<const f32x4*>(type0 + ch * 4);
+            v[c] = a;
+            sum += a[0] + a[1] + a[2] + a[3];
+        } else {
+            v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            const f32x4 d = v[c] - mean;
+            sq += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    uint16_t* out = x + (int64_t)(cu[b] + s) * H;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + ch * 4);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bta + ch * 4);
+            const f32x4 y = (v[c] - mean) * rstd * gg + bb;
+            u32x2 o;
+            o[0] = pack_bf16x2(y[0], y[1]); o[1] = pack_bf16x2(y[2], y[3]);
+            *reinterpret_cast<u32x2*>(out + ch * 4) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row LayerNorm bf16 -> bf16, one wave per row (H <= 1024, H % 8 == 0).  n_rows read from cu[n_seqs].
+__global__ __launch_bounds__(256) void layernorm_kernel(const uint16_t* __restrict__ y, uint16_t* __restrict__ x,
+                                                         const float* __restrict__ g, const float* __restrict__ bta,
+                                                         const int32_t* __restrict__ n_rows_ptr, int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= *n_rows_ptr) return;
+    const uint16_t* in = y + (int64_t)r * H;
+    const int nch = H >> 3;                     // 16-B chunks of 8 bf16
+    float v[2][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            const u32x4 q = *reinterpret_cast<const u32x4*>(in + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unpack_bf16x2(q[e], v[c][2 * e], v[c][2 * e + 1]);
+                sum += v[c][2 * e] + v[c][2 * e + 1];
+            }
+        }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+        if (lane + 64 * c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    uint16_t* out = x + (int64_t)r * H;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(g + ch * 8), g1 = *reinterpret_cast<const f32x4*>(g + ch * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bta + ch * 8), b1 = *reinterpret_cast<const f32x4*>(bta + ch * 8 + 4);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (v[c][e] - mean) * rstd * g0[e] + b0[e];
+                o[e + 4] = (v[c][e + 4] - mean) * rstd * g1[e] + b1[e];
+            }
+            u32x4 q;
+            q[0] = pack_bf16x2(o[0], o[1]); q[1] = pack_bf16x2(o[2], o[3]);
+            q[2] = pack_bf16x2(o[4], o[5]); q[3] = pack_bf16x2(o[6], o[7]);
+            *reinterpret_cast<u32x4*>(out + ch * 8) = q;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Fused attention for one (sequence b, head h, block of 32*NW queries).
+//   scores^T tile [32 keys x 32 queries] = K_tile . Q^T  via mfma_f32_32x32x16_bf16 (A = K rows from LDS,
+//   B = Q fragments held in registers): the query sits on the lane, the keys in the 16 accumulator
+//   registers, so softmax statistics are lane-local (+ one exchange between lane halves) and the
+//   bf16-packed probabilities are directly the B operand of  O^T += V^T . P^T  (no LDS round trip).
+//   V is transposed once per block while staging into LDS (key order inside each 16-key group permuted
+//   to the MFMA k order: [0-3, 8-11 | 4-7, 12-15]) so the A-operand read is one ds_read_b128.
+//   s = q.k * scale + bias[key - query] (MPNet), keys >= len masked; online softmax in base 2.
+// LDS (dynamic): K [Lk][DH] bf16 (16-B chunk XOR-swizzled), V^T [DH][Lk+8] bf16,
+//                4 shifted copies of the Toeplitz bias row [2*Lk+8] f32 (aligned float4 reads).
+template <int DH> struct AttnSmem {
+    static __host__ __device__ int k_bytes(int Lk) { return Lk * DH * 2; }
+    static __host__ __device__ int vt_stride(int Lk) { return Lk + 8; }
+    static __host__ __device__ int vt_bytes(int Lk) { return DH * (Lk + 8) * 2; }
+    static __host__ __device__ int bias_stride(int Lk) { return 2 * Lk + 8; }
+    static __host__ __device__ int bias_bytes(int Lk, bool has) { return has ? 4 * (2 * Lk + 8) * 4 : 0; }
+    static __host__ __device__ int total(int Lk, bool has) { return k_bytes(Lk) + vt_bytes(Lk) + bias_bytes(Lk, has); }
+};
+
+#define ARX_BIAS_CENTER 640          // global bias table: [heads][2*640+1], entry d + 640 for d in [-640, 640]
+#define ARX_BIAS_ROW (2 * ARX_BIAS_CENTER + 1)
+
+template <int DH, bool HAS_BIAS, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
+                                                             const int32_t* __restrict__ cu,
+                                                             const float* __restrict__ bias_tbl,   // pre-multiplied by log2(e)
+                                                             int H, float scale_log2e) {
+    constexpr int NT = NW * 64;
+    constexpr int CPR = DH / 8;                 // 16-B chunks per K row
+    constexpr int RPB = 256 / (DH * 2);         // K rows per 256-B bank row
+    constexpr int KS = DH / 16;                 // QK^T k-steps
+    constexpr int DB = DH / 32;                 // 32-row blocks of O^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int t0 = cu[b];
+    const int L = cu[b + 1] - t0;
+    const int q0 = blockIdx.x * (32 * NW);
+    if (q0 >= L) return;
+    const int Lk = (L + 31) & ~31;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t ld = 3 * (int64_t)H;
+    const uint16_t* Qg = qkv + (int64_t)t0 * ld + h * DH;
+    const uint16_t* Kg = Qg + H;
+    const uint16_t* Vg = Qg + 2 * H;
+
+    char* Ks = smem;
+    uint16_t* Vt = reinterpret_cast<uint16_t*>(smem + AttnSmem<DH>::k_bytes(Lk));
+    float* Bs = reinterpret_cast<float*>(smem + AttnSmem<DH>::k_bytes(Lk) + AttnSmem<DH>::vt_bytes(Lk));
+    const int vts = AttnSmem<DH>::vt_stride(Lk);
+    const int bst = AttnSmem<DH>::bias_stride(Lk);
+
+    // ---- stage K (swizzled), V^T (transposed, key-permuted), bias copies
+    for (int cid = tid; cid < Lk * CPR; cid += NT) {
+        const int row = cid / CPR, pc = cid % CPR;
+        const int c = pc ^ ((row / RPB) & (CPR - 1));
+        u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
+        if (row < L) {
+            kv = *reinterpret_cast<const u32x4*>(Kg + (int64_t)row * ld + c * 8);
+            vv = *reinterpret_cast<const u32x4*>(Vg + (int64_t)row * ld + pc * 8);
+        }
+        *reinterpret_cast<u32x4*>(Ks + (int64_t)cid * 16) = kv;
+        // V[row][pc*8 + e] -> Vt[pc*8 + e][pos(row)]
+        const int k16 = row & 15;
+        const int pos = (row & ~15) + (((k16 >> 2) & 1) << 3) + ((k16 >> 3) << 2) + (k16 & 3);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Vt[(pc * 8 + 2 * e) * vts + pos] = (uint16_t)(vv[e] & 0xffffu);
+            Vt[(pc * 8 + 2 * e + 1) * vts + pos] = (uint16_t)(vv[e] >> 16);
+        }
+    }
+    if (HAS_BIAS) {
+        const float* bt = bias_tbl + (int64_t)h * ARX_BIAS_ROW + ARX_BIAS_CENTER;
+        for (int i = tid; i < 4 * bst; i += NT) {
+            const int c = i / bst, j = i % bst;
+            int d = j + c - Lk;                       // key - query
+            d = d < -ARX_BIAS_CENTER ? -ARX_BIAS_CENTER : (d > ARX_BIAS_CENTER ? ARX_BIAS_CENTER : d);
+            Bs[i] = bt[d];
+        }
+    }
+    __syncthreads();
+
+    // ---- per-wave: 32 queries
+    const int qw = q0 + wid * 32;
+    if (qw >= L) return;                              // no barriers below
+    const int ql = lane & 31, hh = lane >> 5;
+    const int q = qw + ql;                            // this lane's query (may be >= L: computed, not stored)
+    const int qc = q < L ? q : L - 1;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)qc * ld + ks * 16 + hh * 8);
+
+    f32x16 o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // bias: copy c = (-q) & 3, aligned float4 index (kb - q + Lk - c) for key base kb (multiple of 4)
+    const int bc = (4 - (qc & 3)) & 3;
+    const float* brow = Bs + bc * bst + (Lk - qc - bc);
+    const int krow_sw = ((ql / RPB) & (CPR - 1));     // swizzle term of K row (32*kt + ql): 32*kt/RPB = 0 mod CPR
+
+    const int nkt = Lk >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const char* krow = Ks + (int64_t)(kt * 32 + ql) * (DH * 2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((2 * ks + hh) ^ krow_sw) << 4));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        // scale + bias + mask; register r <-> key = 32*kt + (r&3) + 8*(r>>2) + 4*hh
+        float mx = -INFINITY;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int kb = kt * 32 + 8 * g4 + 4 * hh;
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (HAS_BIAS) bv = *reinterpret_cast<const f32x4*>(brow + kb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = s[g4 * 4 + e] * scale_log2e + bv[e];
+                v = (kb + e < L) ? v : -INFINITY;
+                s[g4 * 4 + e] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);           // finite: key 0 of tile 0 is always valid
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - m_new); rs += s[r]; }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        // P^T fragments: k-step ss uses registers 8ss..8ss+7
+        bf16x8 pf[2];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[ss][e] = (bf16_t)s[8 * ss + e];
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+            const uint16_t* vrow = Vt + (int64_t)(d * 32 + ql) * vts + kt * 32 + hh * 8;
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vrow + ss * 16);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ss], o[d], 0, 0, 0);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (q < L) {
+        uint16_t* orow = ctx + (int64_t)(t0 + q) * H + h * DH;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 w2;
+                w2[0] = pack_bf16x2(o[d][g4 * 4 + 0] * inv, o[d][g4 * 4 + 1] * inv);
+                w2[1] = pack_bf16x2(o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv);
+                *reinterpret_cast<u32x2*>(orow + d * 32 + 8 * g4 + 4 * hh) = w2;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Pool (masked mean over the sequence's tokens, or CLS row) + optional L2 normalise.
+// One block (256 thr) per sequence; writes f32 and/or fp16 rows.
+__global__ __launch_bounds__(256) void pool_norm_kernel(const uint16_t* __restrict__ x, const int32_t* __restrict__ cu,
+                                                         int H, int pool_mode, int normalize,
+                                                         float* __restrict__ out32, int64_t ld32,
+                                                         f16_t* __restrict__ out16, int64_t ld16) {
+    __shared__ float acc_s[4][1024];
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int t0 = cu[b], L = cu[b + 1] - t0;
+    const int nch = H >> 3;
+    float a[2][8];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[c][e] = 0.f;
+    const int nrows = (pool_mode == ARX_POOL_CLS) ? (L > 0 ? 1 : 0) : L;
+    for (int r = w; r < nrows; r += 4) {
+        const uint16_t* in = x + (int64_t)(t0 + r) * H;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ch = lane + 64 * c;
+            if (ch < nch) {
+                const u32x4 q = *reinterpret_cast<const u32x4*>(in + ch * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float lo, hi;
+                    unpack_bf16x2(q[e], lo, hi);
+                    a[c][2 * e] += lo; a[c][2 * e + 1] += hi;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nch)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc_s[w][ch * 8 + e] = a[c][e];
+    }
+    __syncthreads();
+    // thread tid owns columns tid, tid+256, ... (H <= 1024)
+    float v[4];
+    float sq = 0.f;
+    const float denom = (pool_mode == ARX_POOL_CLS) ? 1.0f : fmaxf((float)L, 1e-9f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = tid + 256 * c;
+        v[c] = 0.f;
+        if (col < H) {
+            v[c] = (acc_s[0][col] + acc_s[1][col] + acc_s[2][col] + acc_s[3][col]) / denom;
+            sq += v[c] * v[c];
+        }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) red[w] = sq;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float sc = normalize ? 1.0f / fmaxf(nrm, 1e-12f) : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = tid + 256 * c;
+        if (col < H) {
+            const float y = v[c] * sc;
+            if (out32) out32[(int64_t)b * ld32 + col] = y;
+            if (out16) out16[(int64_t)b * ld16 + col] = (f16_t)y;
+        }
+    }
+}
+
+// bf16 [n, H] -> f32 (debug tap)
+__global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = bf16_bits_to_f32(src[i]);
+}
+__global__ void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { bf16_t v = (bf16_t)src[i]; dst[i] = __builtin_bit_cast(uint16_t, v); }
+}

@@ -1,0 +1,210 @@
+"""Host side of the MI355X encoder: the drop-in for the object the reference calls `model`.
+
+The reference's hot loop does (generate_embeddings_parallel.py:146-153)
+
+    model.encode(batch, batch_size=..., normalize_embeddings=True, show_progress_bar=False,
+                 convert_to_numpy=True, convert_to_tensor=False)
+
+and `model.get_sentence_embedding_dimension()` (:169).  `HipSentenceEncoder` exposes exactly those
+two methods with the same argument meaning, so that loop runs unchanged on top of it; underneath,
+token batches go to the HIP kernels through the C ABI (include/arx.h).  PyTorch is used only for
+device memory and streams.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import ARCH_MPNET, EncoderConfig
+from .weights import layer_keys
+
+
+def _dev_ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class HipEncoder:
+    """Token ids -> unit-norm sentence embeddings on one GPU (one handle, one stream user)."""
+
+    def __init__(self, cfg: EncoderConfig, state_dict: Dict[str, np.ndarray], device: Union[str, torch.device] = "cuda:0",
+                 max_tokens: int = 32 * 512, max_seqs: int = 32):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.ArxError("no HIP device visible: the encoder has no CPU path")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self._w: List[torch.Tensor] = []          # keeps device weights alive
+        self._handle = C.c_void_p(None)
+        self._cap = (0, 0)
+        self._upload(state_dict)
+        self._ensure_capacity(max_tokens, max_seqs)
+
+    # ---- weights --------------------------------------------------------------------------------
+    def _f32(self, a: np.ndarray) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+        self._w.append(t)
+        return t
+
+    def _bf16(self, a: np.ndarray) -> torch.Tensor:
+        # round-to-nearest-even on device via the library's own converter
+        src = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+        dst = torch.empty(src.shape, dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.arx_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(),
+                                            torch.cuda.current_stream().cuda_stream), "arx_f32_to_bf16")
+        self._w.append(dst)
+        return dst
+
+    def _upload(self, sd: Dict[str, np.ndarray]):
+        cfg = self.cfg
+        self._layers_c = (_lib.LayerWeightsC * cfg.layers)()
+        for i in range(cfg.layers):
+            k = layer_keys(cfg, i)
+            wqkv = np.concatenate([sd[k["q"] + ".weight"], sd[k["k"] + ".weight"], sd[k["v"] + ".weight"]], 0)
+            bqkv = np.concatenate([sd[k["q"] + ".bias"], sd[k["k"] + ".bias"], sd[k["v"] + ".bias"]], 0)
+            L = self._layers_c[i]
+            L.w_qkv = self._bf16(wqkv).data_ptr(); L.b_qkv = self._f32(bqkv).data_ptr()
+            L.w_o = self._bf16(sd[k["o"] + ".weight"]).data_ptr(); L.b_o = self._f32(sd[k["o"] + ".bias"]).data_ptr()
+            L.ln1_g = self._f32(sd[k["ln1"] + ".weight"]).data_ptr(); L.ln1_b = self._f32(sd[k["ln1"] + ".bias"]).data_ptr()
+            L.w_fc1 = self._bf16(sd[k["fc1"] + ".weight"]).data_ptr(); L.b_fc1 = self._f32(sd[k["fc1"] + ".bias"]).data_ptr()
+            L.w_fc2 = self._bf16(sd[k["fc2"] + ".weight"]).data_ptr(); L.b_fc2 = self._f32(sd[k["fc2"] + ".bias"]).data_ptr()
+            L.ln2_g = self._f32(sd[k["ln2"] + ".weight"]).data_ptr(); L.ln2_b = self._f32(sd[k["ln2"] + ".bias"]).data_ptr()
+        w = _lib.EncoderWeightsC()
+        w.word_emb = self._f32(sd["embeddings.word_embeddings.weight"]).data_ptr()
+        w.pos_emb = self._f32(sd["embeddings.position_embeddings.weight"]).data_ptr()
+        w.emb_ln_g = self._f32(sd["embeddings.LayerNorm.weight"]).data_ptr()
+        w.emb_ln_b = self._f32(sd["embeddings.LayerNorm.bias"]).data_ptr()
+        if cfg.arch == ARCH_MPNET:
+            w.type_emb = None
+            w.rel_bias = self._f32(sd["encoder.relative_attention_bias.weight"]).data_ptr()
+        else:
+            w.type_emb = self._f32(sd["embeddings.token_type_embeddings.weight"][0]).data_ptr()
+            w.rel_bias = None
+        w.layers = C.cast(self._layers_c, C.POINTER(_lib.LayerWeightsC))
+        self._weights_c = w
+        c = _lib.EncoderConfigC(cfg.arch, cfg.vocab_size, cfg.hidden, cfg.layers, cfg.heads, cfg.ffn, cfg.max_pos,
+                                cfg.pool, cfg.pad_id, cfg.rel_buckets, cfg.rel_max_distance, cfg.ln_eps)
+        self._cfg_c = c
+        torch.cuda.synchronize(self.device)
+
+    def _ensure_capacity(self, max_tokens: int, max_seqs: int):
+        if max_tokens <= self._cap[0] and max_seqs <= self._cap[1]:
+            return
+        max_tokens = max(max_tokens, self._cap[0]); max_seqs = max(max_seqs, self._cap[1])
+        self.close()
+        h = C.c_void_p(None)
+        _lib.check(self.lib.arx_encoder_create(C.byref(self._cfg_c), C.byref(self._weights_c), max_tokens, max_seqs,
+                                               C.byref(h)), "arx_encoder_create")
+        self._handle = h
+        self._cap = (max_tokens, max_seqs)
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            torch.cuda.synchronize(self.device)
+            self.lib.arx_encoder_destroy(self._handle)
+            self._handle = C.c_void_p(None)
+            self._cap = (0, 0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- forward --------------------------------------------------------------------------------
+    def forward_tokens(self, ids: torch.Tensor, lens: torch.Tensor, max_len: int, total_tokens: int,
+                       out: Optional[torch.Tensor] = None, out_f16: Optional[torch.Tensor] = None,
+                       normalize: bool = True) -> Optional[torch.Tensor]:
+        """ids int32 [B, S] (device), lens int32 [B] (device) -> f32 [B, H] (device).  Launches on the
+        current torch stream; `out_f16` (fp16 [B, >=H], e.g. a slice of the corpus shard) is written in place."""
+        B, S = ids.shape
+        assert ids.dtype == torch.int32 and lens.dtype == torch.int32 and ids.is_contiguous() and lens.is_contiguous()
+        self._ensure_capacity(total_tokens, B)
+        if out is None and out_f16 is None:
+            out = torch.empty((B, self.cfg.hidden), dtype=torch.float32, device=self.device)
+        rc = self.lib.arx_encoder_forward(
+            self._handle, ids.data_ptr(), S, lens.data_ptr(), B, max_len, total_tokens,
+            _dev_ptr(out), 0 if out is None else out.stride(0),
+            _dev_ptr(out_f16), 0 if out_f16 is None else out_f16.stride(0),
+            1 if normalize else 0, torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "arx_encoder_forward")
+        return out
+
+    def encode_tokens(self, ids: np.ndarray, lens: np.ndarray, normalize: bool = True) -> torch.Tensor:
+        """Right-padded ids [B, S] + lens [B] (host arrays) -> f32 [B, H] device tensor."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        if ids.shape[0] == 0:
+            return torch.empty((0, self.cfg.hidden), dtype=torch.float32, device=self.device)
+        max_len = max(int(lens.max()), 1)
+        total = max(int(lens.sum()), 1)
+        d_ids = torch.from_numpy(ids).to(self.device, non_blocking=True)
+        d_lens = torch.from_numpy(lens).to(self.device, non_blocking=True)
+        return self.forward_tokens(d_ids, d_lens, max_len, total, normalize=normalize)
+
+    def encode_ragged(self, seqs: Sequence[Sequence[int]], batch_size: int = 256, normalize: bool = True) -> np.ndarray:
+        """Token-id lists -> f32 [n, H] numpy, input order preserved.  Sorted by length (descending, as
+        sentence-transformers does) so each forward pads to a similar length; results do not depend on
+        batch composition (key-padding mask), so the re-bucketing is invisible to the caller."""
+        n = len(seqs)
+        out = np.zeros((n, self.cfg.hidden), np.float32)
+        if n == 0:
+            return out
+        order = sorted(range(n), key=lambda i: -len(seqs[i]))
+        for s0 in range(0, n, batch_size):
+            idx = order[s0:s0 + batch_size]
+            lens = np.array([len(seqs[i]) for i in idx], np.int32)
+            S = max(int(lens.max()), 1)
+            ids = np.full((len(idx), S), self.cfg.pad_id, np.int32)
+            for r, i in enumerate(idx):
+                ids[r, :lens[r]] = seqs[i]
+            out[idx] = self.encode_tokens(ids, lens, normalize).cpu().numpy()
+        return out
+
+    def tap_hidden(self, ids: np.ndarray, lens: np.ndarray, layer: int) -> np.ndarray:
+        """Parity tap: packed hidden state [sum(lens), H] f32 after `layer` (0 = embeddings)."""
+        _lib.check(self.lib.arx_encoder_set_tap(self._handle, layer), "arx_encoder_set_tap")
+        self.encode_tokens(ids, lens)
+        T = int(np.asarray(lens).sum())
+        dst = torch.empty((T, self.cfg.hidden), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.arx_encoder_debug_hidden(self._handle, layer, dst.data_ptr(), T,
+                                                     torch.cuda.current_stream().cuda_stream), "arx_encoder_debug_hidden")
+        _lib.check(self.lib.arx_encoder_set_tap(self._handle, -1), "arx_encoder_set_tap")
+        return dst.cpu().numpy()
+
+
+class HipSentenceEncoder:
+    """`SentenceTransformer`-shaped facade: tokenizer + HipEncoder.
+
+    encode(sentences, batch_size=32, normalize_embeddings=False, convert_to_numpy=True,
+           convert_to_tensor=False, show_progress_bar=None)  -> np.ndarray [n, D] float32
+    mirrors the call at generate_embeddings_parallel.py:146-153 / :160-165."""
+
+    def __init__(self, cfg: EncoderConfig, state_dict, tokenizer, device="cuda:0", max_batch: int = 1024):
+        self.cfg = cfg
+        self.tokenizer = tokenizer
+        self.max_seq_length = cfg.max_seq_length
+        self.encoder = HipEncoder(cfg, state_dict, device=device)
+        self.max_batch = max_batch
+
+    def get_sentence_embedding_dimension(self) -> int:
+        return self.cfg.hidden
+
+    def tokenize(self, sentences: Sequence[str]) -> List[List[int]]:
+        return self.tokenizer.encode_batch(list(sentences), self.max_seq_length)
+
+    def encode(self, sentences, batch_size: int = 32, show_progress_bar=None, convert_to_numpy: bool = True,
+               convert_to_tensor: bool = False, normalize_embeddings: bool = False, **_ignored):
+        single = isinstance(sentences, str)
+        if single:
+            sentences = [sentences]
+        seqs = self.tokenize(sentences)
+        emb = self.encoder.encode_ragged(seqs, batch_size=max(1, min(batch_size, self.max_batch)),
+                                         normalize=normalize_embeddings)
+        if convert_to_tensor:
+            emb = torch.from_numpy(emb)
+        return emb[0] if single else emb

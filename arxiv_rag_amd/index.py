@@ -1,0 +1,95 @@
+"""HBM-resident brute-force cosine top-k (`retrieval.top_k: 10`, 3-chunks/pipeline/config.yaml:63-64).
+
+One `ShardIndex` per process/GPU holds that rank's rows of the fp16 corpus (the rows it encoded; they
+never move).  `search` = local exact top-k through the C ABI; `search_distributed` adds the single
+exchange step of the path: an all-gather of the per-shard [Q, k] partial results over RCCL, then a
+merge kernel (ties -> lower global row id).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+class ShardIndex:
+    def __init__(self, corpus_f16: torch.Tensor, idx_base: int = 0):
+        assert corpus_f16.is_cuda and corpus_f16.dtype == torch.float16 and corpus_f16.dim() == 2
+        assert corpus_f16.stride(1) == 1 and corpus_f16.stride(0) == corpus_f16.shape[1], "corpus must be dense row-major"
+        self.lib = _lib.load()
+        self.corpus = corpus_f16
+        self.n_rows, self.dim = corpus_f16.shape
+        self.idx_base = int(idx_base)
+        self._ws: Optional[torch.Tensor] = None
+
+    def _workspace(self, nq: int, k: int) -> torch.Tensor:
+        need = self.lib.arx_topk_workspace_bytes(self.n_rows, nq, self.dim, k)
+        if need < 0:
+            raise _lib.ArxError(f"unsupported search shape n_rows={self.n_rows} nq={nq} dim={self.dim} k={k}")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
+        return self._ws
+
+    def search(self, queries_f16: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
+        """queries fp16 [Q, D] (device) -> (scores f32 [Q, k], ids int64 [Q, k]); ids are global
+        (local row + idx_base); score desc, ties -> lower id; (-inf, -1) pads when k > n_rows."""
+        q = queries_f16
+        assert q.is_cuda and q.dtype == torch.float16 and q.dim() == 2 and q.shape[1] == self.dim and q.is_contiguous()
+        nq = q.shape[0]
+        scores = torch.empty((nq, k), dtype=torch.float32, device=q.device)
+        ids = torch.empty((nq, k), dtype=torch.int64, device=q.device)
+        if nq == 0:
+            return scores, ids
+        if self.n_rows == 0:
+            scores.fill_(float("-inf")); ids.fill_(-1)
+            return scores, ids
+        ws = self._workspace(nq, k)
+        rc = self.lib.arx_topk_search(self.corpus.data_ptr(), self.n_rows, q.data_ptr(), nq, self.dim, k,
+                                      scores.data_ptr(), ids.data_ptr(), self.idx_base, ws.data_ptr(), ws.numel(),
+                                      torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "arx_topk_search")
+        return scores, ids
+
+    def search_distributed(self, queries_f16: torch.Tensor, k: int = 10, group=None):
+        """Every rank passes the SAME queries; returns the global top-k on every rank."""
+        import torch.distributed as dist
+        s, i = self.search(queries_f16, k)
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return s, i
+        P = dist.get_world_size(group)
+        all_s = torch.empty((P,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+        all_i = torch.empty((P,) + tuple(i.shape), dtype=i.dtype, device=i.device)
+        dist.all_gather_into_tensor(all_s, s, group=group)
+        dist.all_gather_into_tensor(all_i, i, group=group)
+        return merge_partials(all_s, all_i, k)
+
+
+def merge_partials(all_scores: torch.Tensor, all_ids: torch.Tensor, k: int):
+    """[P, Q, k] partial lists (device) -> merged [Q, k] via the HIP merge kernel."""
+    lib = _lib.load()
+    P, nq, kk = all_scores.shape
+    assert kk == k and all_scores.is_contiguous() and all_ids.is_contiguous()
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=all_scores.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=all_scores.device)
+    rc = lib.arx_topk_merge(all_scores.data_ptr(), all_ids.data_ptr(), P, nq, k, out_s.data_ptr(), out_i.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "arx_topk_merge")
+    return out_s, out_i
+
+
+def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
+    """rows [r*ceil(N/P), min(N, (r+1)*ceil(N/P)))  (SURVEY.md §8e)."""
+    per = (n_total + world - 1) // world
+    lo = min(n_total, rank * per)
+    return lo, min(n_total, lo + per)
+
+
+def fill_unit_rows(n_rows: int, dim: int, seed: int, device="cuda:0") -> torch.Tensor:
+    """Synthetic corpus/queries generated directly in HBM (bench cfg 3)."""
+    lib = _lib.load()
+    t = torch.empty((n_rows, dim), dtype=torch.float16, device=device)
+    _lib.check(lib.arx_fill_unit_rows_f16(t.data_ptr(), n_rows, dim, seed, torch.cuda.current_stream().cuda_stream),
+               "arx_fill_unit_rows_f16")
+    return t

@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on rank 0.
+
+Step = one pass of the encode hot path over one batch: 1024 synthetic chunks x exactly 256 token ids
+(BASELINE.json configs[1]: all-mpnet-base-v2 shape, bf16 weights/activations, fp32 accumulate), ids already
+resident in HBM, output = unit-norm fp16 rows written into the rank's HBM corpus shard.
+value = whole-job chunks/s (all ranks; weak scaling: every rank encodes its own batches, no collective on
+the encode path).  Extra objects on the same line:
+  roofline      dominant kernel (FFN-1 GEMM), algorithmic FLOPs per launch / mean launch time (hipEvents
+                recorded by the library on the launch stream during the timed region), vs 2.5 PFLOP/s bf16
+  encode        whole-forward MFMA fraction + per-kernel-class time split
+  search        QPS@top-10 over a 10 M x 768 fp16 shard per rank (configs[2]) at several query-batch sizes,
+                pass-A HBM roofline fraction; with N > 1 the per-shard partials are all-gathered over RCCL
+  cpu_baseline  the numpy oracle (oracle/encoder_oracle.py) timed on this box's host cores on a bounded sample
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MFMA_PEAK_BF16 = 2.5e15       # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def flops_per_chunk(cfg, S):
+    H, F, L = cfg.hidden, cfg.ffn, cfg.layers
+    return L * (8 * S * H * H + 4 * S * H * F + 4 * S * S * H)
+
+
+def cpu_baseline(cfg, sd, S, budget_s=20.0):
+    """Oracle on host cores: batches of 8 chunks x S tokens until ~budget_s is spent (>= 1 timed batch)."""
+    from oracle import encoder_oracle as EO
+    rs = np.random.RandomState(99)
+    B = 8
+    ids = rs.randint(4, cfg.vocab_size - 1, size=(B, S)).astype(np.int64)
+    ids[:, 0] = 0; ids[:, -1] = 2
+    lens = np.full(B, S, np.int64)
+    t0 = time.time(); EO.encode_tokens(sd, cfg, ids[:2], lens[:2]); warm = time.time() - t0
+    n, t = 0, 0.0
+    while t < budget_s * 0.6 or n == 0:
+        t0 = time.time(); EO.encode_tokens(sd, cfg, ids, lens); t += time.time() - t0; n += B
+        if t + warm > budget_s:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": round(n / t, 3), "unit": "chunks/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n} chunks x {S} tokens, {cfg.layers}L/{cfg.hidden} fp32 numpy oracle (oracle/encoder_oracle.py), "
+                      f"batch {B}, host has {os.cpu_count()} logical cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--seq-len", type=int, default=256)
+    ap.add_argument("--model", default="all-mpnet-base-v2")
+    ap.add_argument("--search-rows", type=int, default=10_000_000, help="corpus rows per rank (0 = skip search leg)")
+    ap.add_argument("--search-queries", type=int, default=10_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from arxiv_rag_amd import _lib, config as C
+    from arxiv_rag_amd.encoder import HipEncoder
+    from arxiv_rag_amd.index import ShardIndex, fill_unit_rows
+    from arxiv_rag_amd.weights import seeded_state_dict
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    cfg = C.PRESETS[args.model]
+    B, S, K, W = args.batch, args.seq_len, args.steps, args.warmup
+    sd = seeded_state_dict(cfg, seed=0)                      # N(0, 0.02^2), LN gamma=1 beta=0 (SURVEY §8d cfg 2)
+    enc = HipEncoder(cfg, sd, device=dev, max_tokens=B * S, max_seqs=B)
+
+    # synthetic chunks: ids[0]=<s>=0, ids[S-1]=</s>=2, body ~ U{4..vocab-2}; every step its own batch
+    g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+    ids = torch.randint(4, cfg.vocab_size - 1, (K + W, B, S), generator=g, device=dev, dtype=torch.int32)
+    ids[:, :, 0] = 0; ids[:, :, S - 1] = 2
+    lens = torch.full((B,), S, dtype=torch.int32, device=dev)
+    shard = torch.empty((K * B, cfg.hidden), dtype=torch.float16, device=dev)   # this rank's corpus rows
+
+    def step(i, slot):
+        enc.forward_tokens(ids[i], lens, S, B * S, out=None, out_f16=shard[slot * B:(slot + 1) * B], normalize=True)
+
+    for i in range(W):
+        step(i, 0)
+    _lib.prof_reset(); _lib.prof_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(W + i, i)
+    barrier()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    chunks_per_s = world * K * B / dt
+    prof = _lib.prof_read()
+    norms = shard[:B].float().norm(dim=1)
+    assert torch.isfinite(norms).all() and (norms - 1).abs().max() < 2e-3, "encoder output is not unit-norm"
+
+    T = B * S
+    gemm_flops = {"gemm_qkv": 2 * T * cfg.hidden * 3 * cfg.hidden, "gemm_oproj": 2 * T * cfg.hidden * cfg.hidden,
+                  "gemm_fc1": 2 * T * cfg.hidden * cfg.ffn, "gemm_fc2": 2 * T * cfg.hidden * cfg.ffn,
+                  "attention": 4 * B * S * S * cfg.hidden}
+    kernels = {}
+    for name, (ms, n) in prof.items():
+        if n == 0:
+            continue
+        e = {"launches": n, "ms_per_launch": round(ms / n, 4), "ms_per_step": round(ms / K, 3)}
+        if name in gemm_flops:
+            e["tflops"] = round(gemm_flops[name] / (ms / n * 1e-3) / 1e12, 1)
+        kernels[name] = e
+    dom = "gemm_fc1"
+    ach = gemm_flops[dom] / (prof[dom][0] / prof[dom][1] * 1e-3)
+    traffic = None
+    tj = ROOT / "profiles" / "traffic.json"
+    if tj.exists():
+        try:
+            traffic = json.loads(tj.read_text()).get("gemm_fc1_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "gemm_bf16_kernel<256,256,2,4,*,EPI_BIAS_GELU> (FFN-1: [T,768]x[3072,768]^T)", "bound": "mfma",
+                "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_PEAK_BF16, 4), "traffic": traffic,
+                "flops_per_launch": gemm_flops[dom]}
+    fpc = flops_per_chunk(cfg, S)
+    encode = {"flops_per_chunk": fpc, "mfma_frac_whole_forward": round(chunks_per_s / world * fpc / MFMA_PEAK_BF16, 4),
+              "kernels": kernels}
+
+    # ---- search leg (configs[2]; with N > 1: shard per rank + RCCL all-gather of partial top-k) ----------
+    search = None
+    if args.search_rows > 0:
+        N, nq_all, D = args.search_rows, args.search_queries, cfg.hidden
+        corpus = fill_unit_rows(N, D, seed=7 + rank, device=dev)
+        queries = fill_unit_rows(nq_all, D, seed=11, device=dev)          # same on every rank
+        idx = ShardIndex(corpus, idx_base=rank * N)
+        res = {}
+        for qb in (1, 64, 256, nq_all):
+            qb = min(qb, nq_all)
+            reps = max(1, min(20, (2048 // qb) if qb < nq_all else 1))
+            idx.search_distributed(queries[:qb], 10)                        # warm
+            _lib.prof_reset(); _lib.prof_enable(True)
+            barrier(); t0 = time.perf_counter()
+            for r in range(reps):
+                q0 = (r * qb) % max(1, nq_all - qb + 1)
+                s_, i_ = idx.search_distributed(queries[q0:q0 + qb], 10)
+            barrier(); dts = time.perf_counter() - t0
+            _lib.prof_enable(False)
+            if world > 1:
+                tm = torch.tensor([dts], dtype=torch.float64, device=dev); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dts = float(tm.item())
+            p = _lib.prof_read()
+            gms, gn = p["search_groupmax"]
+            passes_bytes = N * D * 2
+            res[f"Qb={qb}"] = {"qps": round(reps * qb / dts, 1), "ms_per_batch": round(dts / reps * 1e3, 3),
+                               "passA_ms_per_launch": round(gms / gn, 4), "passA_launches_per_batch": gn // reps,
+                               "passA_hbm_GBps": round(passes_bytes / (gms / gn * 1e-3) / 1e9, 1),
+                               "passA_hbm_frac": round(passes_bytes / (gms / gn * 1e-3) / HBM_PEAK, 4),
+                               "passA_tflops": round(2 * min(qb, 1024) * N * D / (gms / gn * 1e-3) / 1e12, 1),
+                               "select_ms": round(p["search_select"][0] / reps, 3), "rescore_ms": round(p["search_rescore"][0] / reps, 3)}
+        search = {"workload": f"{N} x {D} fp16 rows per rank, {nq_all} queries, k=10, world {world}", "results": res}
+        del corpus, idx
+        torch.cuda.empty_cache()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, sd, S, args.cpu_budget)
+
+    if rank == 0:
+        out = {
+            "metric": "chunks embedded/sec + QPS@top-10, all-mpnet-base-v2 768-d, 1/2/4/8 MI355X",
+            "value": round(chunks_per_s, 1), "unit": "chunks/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {args.model} shape, {B} chunks x {S} token ids per step per GPU, "
+                                   f"encode-only (embed+{cfg.layers} layers+mean-pool+L2 -> fp16 corpus rows)",
+                       "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
+                       "weights": "seeded N(0,0.02^2), seed 0"},
+            "roofline": roofline, "cpu_baseline": cpu, "encode": encode, "search": search,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/*
+ * arx.h — C ABI of the MI355X-native embed + retrieve hot path (libarx_hip.so).
+ *
+ * This is the replacement surface for the arithmetic the reference reaches through
+ * `SentenceTransformer.encode(...)`
+ *   /root/reference/4-embed/generation/generate_embeddings_parallel.py:146-153 (batch encode)
+ *   /root/reference/4-embed/generation/generate_embeddings_parallel.py:160-165 (per-item retry)
+ *   /root/reference/3-chunks/pipeline/src/processors/text_processor.py:1383-1396 (semantic chunker)
+ * plus the cosine top-k step the reference configures but never implements
+ *   /root/reference/3-chunks/pipeline/config.yaml:63-64 (`retrieval.top_k: 10`)
+ *   /root/reference/3-chunks/pipeline/src/processors/text_processor.py:1601-1605 (cosine helper).
+ * The reference has no FFI of its own (it is pure Python); INTEGRATION.md shows the ctypes stub a
+ * maintainer would add at those call sites.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "device" is a HIP device pointer owned by the CALLER
+ *     (e.g. a PyTorch-ROCm tensor's data_ptr); the library never allocates outputs.
+ *   - an opaque handle owns only its private workspace (create/destroy).
+ *   - every launch goes on the caller's hipStream_t (passed as void*); no hidden synchronisation.
+ *   - return 0 on success, negative on error; arx_last_error() gives the thread-local message.
+ *   - one host thread per handle.
+ */
+#ifndef ARX_H
+#define ARX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARX_VERSION 100            /* 0.1.0 */
+
+#define ARX_OK            0
+#define ARX_ERR_ARG      -1        /* bad argument / unsupported shape */
+#define ARX_ERR_HIP      -2        /* HIP runtime error */
+#define ARX_ERR_CAPACITY -3        /* batch exceeds the handle's workspace */
+
+#define ARX_ARCH_MPNET 0           /* relative-position bias, pad-aware position ids */
+#define ARX_ARCH_BERT  1           /* absolute positions + token type 0 */
+#define ARX_POOL_MEAN  0
+#define ARX_POOL_CLS   1
+
+typedef struct {
+    int32_t arch;                  /* ARX_ARCH_* */
+    int32_t vocab_size;
+    int32_t hidden;                /* H: multiple of 64 */
+    int32_t layers;
+    int32_t heads;                 /* H / heads must be 32 or 64 */
+    int32_t ffn;                   /* F: multiple of 64 */
+    int32_t max_pos;               /* rows of the position table */
+    int32_t pool;                  /* ARX_POOL_* */
+    int32_t pad_id;                /* MPNet 1, BERT 0 */
+    int32_t rel_buckets;           /* MPNet: 32 */
+    int32_t rel_max_distance;      /* MPNet: 128 */
+    float   ln_eps;
+} arx_encoder_config;
+
+/* All weight pointers: device memory, caller-owned, must outlive the handle.
+ * Matrices are nn.Linear layout [out, in] row-major, bf16 (uint16 storage).  Vectors are f32. */
+typedef struct {
+    const void*  w_qkv;            /* [3H, H] bf16: rows 0..H-1 = q, H..2H-1 = k, 2H..3H-1 = v */
+    const float* b_qkv;            /* [3H] */
+    const void*  w_o;              /* [H, H] bf16 */
+    const float* b_o;              /* [H] */
+    const float* ln1_g; const float* ln1_b;   /* attention output LayerNorm [H] */
+    const void*  w_fc1;            /* [F, H] bf16 */
+    const float* b_fc1;            /* [F] */
+    const void*  w_fc2;            /* [H, F] bf16 */
+    const float* b_fc2;            /* [H] */
+    const float* ln2_g; const float* ln2_b;   /* output LayerNorm [H] */
+} arx_layer_weights;
+
+typedef struct {
+    const float* word_emb;         /* [vocab, H] f32 */
+    const float* pos_emb;          /* [max_pos, H] f32 */
+    const float* type_emb;         /* [H] f32: BERT token_type row 0; NULL for MPNet */
+    const float* emb_ln_g; const float* emb_ln_b;   /* [H] */
+    const float* rel_bias;         /* [rel_buckets, heads] f32 (HF encoder.relative_attention_bias.weight); NULL for BERT */
+    const arx_layer_weights* layers;   /* host array of `layers` entries */
+} arx_encoder_weights;
+
+typedef struct arx_encoder arx_encoder;
+
+int32_t     arx_version(void);
+const char* arx_last_error(void);
+
+/* MPNet relative-position bucket of (key_pos - query_pos) — host function, exported so the table
+ * the kernels consume can be checked against the golden vectors without a GPU. */
+int32_t arx_mpnet_bucket(int32_t relative_position, int32_t num_buckets, int32_t max_distance);
+
+/* Workspace bytes a handle for (cfg, max_tokens, max_seqs) allocates. */
+int64_t arx_encoder_workspace_bytes(const arx_encoder_config* cfg, int32_t max_tokens, int32_t max_seqs);
+
+/* Build a handle: validates shapes, allocates the private workspace (activations for up to
+ * max_tokens packed tokens / max_seqs sequences), precomputes the relative-position table. */
+int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_encoder_weights* w,
+                           int32_t max_tokens, int32_t max_seqs, arx_encoder** out);
+void    arx_encoder_destroy(arx_encoder* h);
+
+/* Encode one batch of token sequences -> unit-norm sentence embeddings.
+ *   ids   device int32 [n_seqs, seq_stride]: right-padded token ids (pad beyond lens[i] is ignored)
+ *   lens  device int32 [n_seqs]: valid tokens per row (0 <= lens[i] <= max_len <= 512)
+ *   total_tokens  host-side upper bound on sum(lens) (exact sum is best; n_seqs*max_len always valid)
+ *   out_f32  device float  [n_seqs, out_stride] or NULL
+ *   out_f16  device fp16   [n_seqs, out16_stride] or NULL   (corpus-shard row, written in place)
+ *   normalize  1: x / max(||x||, 1e-12)   0: raw pooled vector
+ * Semantics = SentenceTransformer.encode(..., normalize_embeddings=True) on the same token ids:
+ * encoder forward, masked mean (or CLS) pool, L2 normalise.  Rows with lens[i] == 0 give zeros. */
+int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32_t seq_stride,
+                            const int32_t* lens, int32_t n_seqs, int32_t max_len, int32_t total_tokens,
+                            float* out_f32, int64_t out_stride,
+                            void* out_f16, int64_t out16_stride,
+                            int32_t normalize, void* stream);
+
+/* Debug / parity tap: copy the packed hidden state after `layer` (0 = embeddings, L = last) as f32
+ * [total_tokens, H] into dst (device).  Valid after a forward on the same stream. */
+int32_t arx_encoder_debug_hidden(arx_encoder* h, int32_t layer_slot, float* dst, int32_t n_tokens, void* stream);
+/* Ask the next forward() to snapshot the hidden state after `layer` (-1 = off). */
+int32_t arx_encoder_set_tap(arx_encoder* h, int32_t layer);
+
+/* ---- brute-force cosine top-k over an HBM-resident fp16 shard ------------------------------------
+ *   corpus  device fp16 [n_rows, dim] row-major (unit rows => dot product = cosine), dim % 64 == 0
+ *   queries device fp16 [n_queries, dim]
+ *   out_scores device f32 [n_queries, k]; out_ids device int64 [n_queries, k] = local row + idx_base
+ *   order: score descending, ties -> lower row index; if k > n_rows the tail is (-inf, -1)
+ *   ws: device workspace of arx_topk_workspace_bytes(...) bytes, caller-owned.  k <= 32. */
+int64_t arx_topk_workspace_bytes(int64_t n_rows, int32_t n_queries, int32_t dim, int32_t k);
+int32_t arx_topk_search(const void* corpus, int64_t n_rows, const void* queries, int32_t n_queries,
+                        int32_t dim, int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base,
+                        void* ws, int64_t ws_bytes, void* stream);
+
+/* Merge P partial top-k lists (e.g. the all-gathered per-shard results) into the global top-k.
+ *   scores f32 [P, n_queries, k], ids int64 [P, n_queries, k] (device) -> out [n_queries, k]. */
+int32_t arx_topk_merge(const float* scores, const int64_t* ids, int32_t n_parts, int32_t n_queries,
+                       int32_t k, float* out_scores, int64_t* out_ids, void* stream);
+
+/* ---- small device helpers the host code needs (all on `stream`) -------------------------------- */
+/* f32 [n] -> bf16 [n] round-to-nearest-even (weight upload). */
+int32_t arx_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* L2-normalised N(0,1) rows in fp16, generated on device from (seed, row index): bench cfg 3. */
+int32_t arx_fill_unit_rows_f16(void* dst, int64_t n_rows, int32_t dim, uint64_t seed, void* stream);
+
+/* ---- live per-kernel timing (bench.py roofline leg) ----------------------------------------------
+ * When enabled, every launch of a hot kernel class is bracketed by hipEvents recorded on the launch
+ * stream; arx_prof_read synchronises on them and returns the summed device time and launch count. */
+#define ARX_K_SEARCH_GROUPMAX 0    /* search pass A: f16 MFMA GEMM + max over 64-row groups */
+#define ARX_K_GEMM_QKV        1
+#define ARX_K_GEMM_OPROJ      2
+#define ARX_K_GEMM_FC1        3
+#define ARX_K_GEMM_FC2        4
+#define ARX_K_ATTENTION       5
+#define ARX_K_LAYERNORM       6
+#define ARX_K_EMBED           7
+#define ARX_K_POOL            8
+#define ARX_K_SEARCH_SELECT   9
+#define ARX_K_SEARCH_RESCORE 10
+#define ARX_K_CLASSES        11
+int32_t arx_prof_enable(int32_t on);
+int32_t arx_prof_reset(void);
+int32_t arx_prof_read(int32_t kernel_class, float* total_ms, int32_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARX_H */
