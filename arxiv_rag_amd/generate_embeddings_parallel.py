@@ -1,0 +1,426 @@
+#!/usr/bin/env python3
+"""Drop-in for stage 4 of arxiv-rag: `4-embed/generation/generate_embeddings_parallel.py` ("GEN").
+
+Same positional argument, flags and defaults (GEN:471-491), same exit codes (GEN:497-499, 527-529, 603-609),
+same `./embeddings_saved/{embeddings.npy, metadata.json, index.json}` layout (GEN:271-321), same
+never-raise-per-chunk policy (GEN:155-177).  What changes is underneath: one process per MI355X
+(`torchrun --nproc-per-node N`), each rank encodes a contiguous shard of the chunk list through the HIP
+encoder and keeps its rows in HBM as its fp16 corpus shard; an optional `--queries` step then serves
+brute-force cosine top-k over the shards (RCCL all-gather of partial top-k).
+
+Additive flags only: --model also takes a local directory; --model-dir, --device-index, --out-dtype,
+--queries, --top-k, --skip-chroma, --max-seq-length.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+import traceback
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+MODEL_CHOICES = ["all-mpnet-base-v2", "all-MiniLM-L6-v2"]          # GEN:474
+
+_model = None
+_model_name = None
+
+
+# --------------------------------------------------------------------------------------------- model
+def init_worker_model(model_name: str, factory: Optional[Callable] = None):
+    """Per-process singleton (GEN:40-65): here one process owns one GPU."""
+    global _model, _model_name
+    if _model is None or _model_name != model_name:
+        if factory is None:
+            from .hub import load_sentence_encoder
+            dev = f"cuda:{os.environ.get('LOCAL_RANK', '0')}"
+            factory = lambda name: load_sentence_encoder(name, device=dev)     # noqa: E731
+        print(f"[rank {os.environ.get('RANK', '0')}] Loading model: {model_name}")
+        _model = factory(model_name)
+        _model_name = model_name
+        print(f"[rank {os.environ.get('RANK', '0')}] Model loaded successfully")
+    return _model
+
+
+def get_worker_model(model_name: str):
+    """GEN:67-74."""
+    return init_worker_model(model_name)
+
+
+# --------------------------------------------------------------------------------------------- load
+def load_chunks_from_file(file_path: Path, min_quality: float = 0.8) -> List[Dict]:
+    """One chunk-JSON file -> its chunks with metadata.quality_score >= min_quality (missing = 0);
+    unreadable files contribute nothing (GEN:76-92)."""
+    kept: List[Dict] = []
+    try:
+        with open(file_path, "r", encoding="utf-8") as fh:
+            doc = json.load(fh)
+        for ch in doc.get("chunks", []):
+            if ch.get("metadata", {}).get("quality_score", 0) >= min_quality:
+                kept.append(ch)
+    except Exception:
+        pass
+    return kept
+
+
+def load_chunks_parallel(output_dir: Path, min_quality: float = 0.8, num_workers: Optional[int] = None) -> List[Dict]:
+    """All `*.json` under the tree except `._*` (GEN:94-129).  Files are visited in SORTED order and
+    results concatenated in that order: the reference's imap_unordered order is not a contract, and a
+    deterministic order is what lets N ranks agree on the shard boundaries."""
+    files = sorted(f for f in Path(output_dir).rglob("*.json") if not f.name.startswith("._"))
+    if num_workers is None:
+        num_workers = max(1, int(mp.cpu_count() * 0.8))
+    print(f"Loading chunks from {len(files):,} files using {num_workers} workers...")
+    out: List[Dict] = []
+    with ThreadPoolExecutor(max_workers=min(num_workers, 64)) as ex:
+        for part in ex.map(lambda f: load_chunks_from_file(f, min_quality), files):
+            if part:
+                out.extend(part)
+    print(f"Loaded {len(out):,} high-quality chunks (quality >= {min_quality})")
+    return out
+
+
+# --------------------------------------------------------------------------------------------- embed
+def generate_embeddings_worker(args: Tuple[List[str], str, int, int]) -> Tuple[int, List[np.ndarray], Optional[str]]:
+    """One work quantum (<= chunks_per_worker texts): sub-batches of batch_size through model.encode;
+    a failed sub-batch is retried per text, a failed text becomes a zero row; never raises (GEN:131-177)."""
+    texts, model_name, batch_size, batch_idx = args
+    try:
+        model = get_worker_model(model_name)
+        if model is None:
+            return (batch_idx, [], "model not loaded")
+        rows: List[np.ndarray] = []
+        for s0 in range(0, len(texts), batch_size):
+            sub = texts[s0:s0 + batch_size]
+            try:
+                rows.extend(model.encode(sub, batch_size=min(batch_size, len(sub)), normalize_embeddings=True,
+                                         show_progress_bar=False, convert_to_numpy=True, convert_to_tensor=False))
+            except Exception:
+                print(f"[rank {os.environ.get('RANK', '0')}] sub-batch {s0 // batch_size} of quantum {batch_idx} failed, trying individual items")
+                for t in sub:
+                    try:
+                        rows.extend(model.encode([t], normalize_embeddings=True, show_progress_bar=False, convert_to_numpy=True))
+                    except Exception:
+                        rows.append(np.zeros(model.get_sentence_embedding_dimension()))
+        return (batch_idx, rows, None)
+    except Exception as e:                                                   # noqa: BLE001
+        msg = f"Error in rank {os.environ.get('RANK', '0')}: {e}"
+        print(msg)
+        traceback.print_exc()
+        return (batch_idx, [], msg)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    per = (n_items + world - 1) // world
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+def generate_embeddings_parallel(chunks: List[Dict], model_name: str = "all-mpnet-base-v2", batch_size: int = 200,
+                                 num_workers: Optional[int] = None, chunks_per_worker: int = 500) -> List[np.ndarray]:
+    """Embedding i <-> chunk i (GEN:179-269).  Quanta of chunks_per_worker texts; with torchrun each rank takes
+    a contiguous range of quanta and the per-rank results are exchanged so every rank returns all N rows
+    (missing quanta -> zero rows, count mismatch -> pad/truncate, as GEN:260-267)."""
+    texts = [c["text"] for c in chunks]
+    dist = _dist()
+    world = dist.get_world_size() if dist else 1
+    rank = dist.get_rank() if dist else 0
+    quanta = [(texts[i:i + chunks_per_worker], model_name, batch_size, qi)
+              for qi, i in enumerate(range(0, len(texts), chunks_per_worker))]
+    print(f"Generating embeddings for {len(texts):,} chunks on {world} GPU(s)...")
+    print(f"Model: {model_name}, Batch size: {batch_size}, Chunks per worker: {chunks_per_worker}")
+    q_lo, q_hi = shard_range(len(quanta), world, rank)
+    done: Dict[int, List[np.ndarray]] = {}
+    errors: List[str] = []
+    for q in quanta[q_lo:q_hi]:
+        idx, rows, err = generate_embeddings_worker(q)
+        if err:
+            errors.append(f"Batch {idx}: {err}")
+        if rows:
+            done[idx] = rows
+        else:
+            print(f"Warning: Batch {idx} produced no embeddings")
+    if dist and world > 1:
+        gathered: List = [None] * world
+        dist.all_gather_object(gathered, (done, errors))
+        done, errors = {}, []
+        for d, e in gathered:
+            done.update(d); errors.extend(e)
+    if errors:
+        print(f"\n⚠️  {len(errors)} batches had errors:")
+        for e in errors[:10]:
+            print(f"  - {e}")
+    embeddings: List[np.ndarray] = []
+    missing = 0
+    for qi in range(len(quanta)):
+        rows = done.get(qi)
+        if rows is not None:
+            embeddings.extend(rows)
+        else:
+            missing += 1
+    if missing:
+        print(f"⚠️  {missing} batches missing, used zero vectors as fallback")
+    print(f"Generated {len(embeddings):,} embeddings")
+    if len(embeddings) != len(texts):
+        print(f"⚠️  Warning: Embedding count ({len(embeddings)}) doesn't match text count ({len(texts)})")
+        if len(embeddings) < len(texts):
+            dim = len(embeddings[0]) if embeddings else 768
+            embeddings.extend([np.zeros(dim)] * (len(texts) - len(embeddings)))
+        else:
+            embeddings = embeddings[:len(texts)]
+    return embeddings
+
+
+# --------------------------------------------------------------------------------------------- write
+def save_embeddings_to_disk_fallback(chunks: List[Dict], embeddings: Sequence, output_dir: str = "./embeddings_saved",
+                                     out_dtype: str = "float64"):
+    """embeddings.npy (float64 C-order [N, D] — the reference's `.tolist()` round trip yields float64),
+    metadata.json (indent=2, ensure_ascii=False), index.json (GEN:271-321).  Streams through a memmap so a
+    5 M x 768 corpus (30.7 GB) never needs a second in-RAM copy."""
+    out = Path(output_dir)
+    out.mkdir(parents=True, exist_ok=True)
+    print(f"\nSaving embeddings to disk: {output_dir}")
+    n = len(embeddings)
+    dim = len(embeddings[0]) if n else 0
+    arr = np.lib.format.open_memmap(out / "embeddings.npy", mode="w+", dtype=np.dtype(out_dtype), shape=(n, dim))
+    step = 65536
+    for s0 in range(0, n, step):
+        arr[s0:s0 + step] = np.asarray(embeddings[s0:s0 + step], dtype=np.dtype(out_dtype))
+    nbytes = arr.nbytes
+    arr.flush()
+    del arr
+    print(f"✅ Saved embeddings to {out / 'embeddings.npy'}")
+    meta = []
+    for i, ch in enumerate(chunks):
+        m = ch.get("metadata", {})
+        meta.append({"chunk_id": ch.get("chunk_id", f"chunk_{i}"), "paper_id": m.get("paper_id"),
+                     "section": m.get("section"), "quality_score": m.get("quality_score"),
+                     "text": ch["text"], "text_length": len(ch["text"])})
+    with open(out / "metadata.json", "w", encoding="utf-8") as fh:
+        json.dump(meta, fh, indent=2, ensure_ascii=False)
+    print(f"✅ Saved metadata to {out / 'metadata.json'}")
+    index = {"total_embeddings": n, "embedding_dimension": dim, "total_size_gb": nbytes / 1024 / 1024 / 1024}
+    with open(out / "index.json", "w", encoding="utf-8") as fh:
+        json.dump(index, fh, indent=2)
+    print(f"✅ Saved {n:,} embeddings ({dim} dimensions)")
+    print(f"   Total size: ~{nbytes / 1024 / 1024 / 1024:.2f} GB")
+
+
+def store_in_chroma_batched(chunks: List[Dict], embeddings: Sequence, db_path: str = "./chroma_db",
+                            collection_name: str = "scientific_papers", batch_size: int = 2000):
+    """Vector-store hand-off (GEN:323-468): ids / documents / metadatas exactly as GEN:404-412, batches of
+    `batch_size`, 3 tries per batch then per-item adds.  Raises ImportError when chromadb is absent."""
+    import chromadb                                                    # noqa: F401  (lazy: optional dependency)
+    n = min(len(chunks), len(embeddings))
+    client = chromadb.PersistentClient(path=db_path)
+    try:
+        coll = client.get_collection(name=collection_name)
+    except Exception:
+        coll = client.create_collection(name=collection_name, metadata={"description": "Scientific paper chunks for RAG"})
+    stored = 0
+    for s0 in range(0, n, batch_size):
+        ids, embs, docs, metas = [], [], [], []
+        for j in range(s0, min(n, s0 + batch_size)):
+            ch, m = chunks[j], chunks[j].get("metadata", {})
+            ids.append(ch.get("chunk_id", f"chunk_{j}"))
+            embs.append(np.asarray(embeddings[j]).tolist())
+            docs.append(ch["text"])
+            metas.append({"paper_id": str(m.get("paper_id", "unknown")), "section": str(m.get("section", "unknown")),
+                          "quality_score": float(m.get("quality_score", 0.0)), "chunk_index": str(m.get("chunk_index", j))})
+        for attempt in range(3):
+            try:
+                coll.add(ids=ids, embeddings=embs, documents=docs, metadatas=metas)
+                stored += len(ids)
+                break
+            except Exception as e:                                     # noqa: BLE001
+                if attempt < 2:
+                    time.sleep(0.5)
+                    continue
+                print(f"Error storing batch {s0 // batch_size}: {e}")
+                for k in range(len(ids)):
+                    try:
+                        coll.add(ids=[ids[k]], embeddings=[embs[k]], documents=[docs[k]], metadatas=[metas[k]])
+                        stored += 1
+                    except Exception:
+                        pass
+    if stored == 0:
+        print("\n❌ Failed to store any embeddings in ChromaDB")
+    else:
+        print(f"✅ Stored {stored:,} embeddings in ChromaDB")
+    return stored
+
+
+# --------------------------------------------------------------------------------------------- search (added step)
+def search_queries(model, chunks: List[Dict], embeddings: Sequence, queries: List[str], top_k: int = 10,
+                   output_dir: str = "./embeddings_saved") -> List[Dict]:
+    """Brute-force cosine top-k (config.yaml:63-64 `top_k: 10`) over the rank's fp16 rows in HBM; with
+    torchrun each rank holds the contiguous row shard it encoded and the partial top-k lists are
+    all-gathered over RCCL and merged."""
+    import torch
+    from .index import ShardIndex, shard_bounds
+    dist = _dist()
+    world = dist.get_world_size() if dist else 1
+    rank = dist.get_rank() if dist else 0
+    n = len(embeddings)
+    lo, hi = shard_bounds(n, world, rank)
+    dev = model.encoder.device
+    shard = torch.from_numpy(np.asarray(embeddings[lo:hi], dtype=np.float16)).to(dev) if hi > lo else \
+        torch.empty((0, model.get_sentence_embedding_dimension()), dtype=torch.float16, device=dev)
+    q = model.encode(queries, batch_size=256, normalize_embeddings=True, convert_to_numpy=True)
+    qd = torch.from_numpy(np.asarray(q, dtype=np.float16)).to(dev)
+    s, i = ShardIndex(shard, idx_base=lo).search_distributed(qd, top_k)
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    results = []
+    for qi, text in enumerate(queries):
+        hits = []
+        for r in range(top_k):
+            j = int(i[qi, r])
+            if j < 0:
+                continue
+            hits.append({"rank": r + 1, "score": float(s[qi, r]), "index": j,
+                         "chunk_id": chunks[j].get("chunk_id", f"chunk_{j}")})
+        results.append({"query": text, "results": hits})
+    if rank == 0:
+        with open(Path(output_dir) / "search_results.json", "w", encoding="utf-8") as fh:
+            json.dump(results, fh, indent=2, ensure_ascii=False)
+        print(f"✅ Saved top-{top_k} results for {len(queries)} queries to {Path(output_dir) / 'search_results.json'}")
+    return results
+
+
+# --------------------------------------------------------------------------------------------- main
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser(description="Generate embeddings on MI355X (drop-in for generate_embeddings_parallel.py)")
+    p.add_argument("input_dir", type=str, help="Input directory (output_improved)")
+    p.add_argument("--model", type=str, default="all-mpnet-base-v2",
+                   help=f"Embedding model: one of {MODEL_CHOICES} (resolved to a LOCAL directory) or a model directory")
+    p.add_argument("--min-quality", type=float, default=0.9, help="Minimum quality score (default: 0.9)")
+    p.add_argument("--batch-size", type=int, default=200, help="Batch size for embedding generation (default: 200)")
+    p.add_argument("--chroma-db", type=str, default="./chroma_db", help="Path to ChromaDB (default: ./chroma_db)")
+    p.add_argument("--collection-name", type=str, default="scientific_papers", help="ChromaDB collection name")
+    p.add_argument("--load-workers", type=int, default=None, help="Number of workers for loading (default: 80%% of CPU cores)")
+    p.add_argument("--embedding-workers", type=int, default=None,
+                   help="Accepted for compatibility; embedding parallelism = one process per GPU (torchrun)")
+    p.add_argument("--store-batch-size", type=int, default=2000, help="Batch size for storing in ChromaDB (default: 2000)")
+    p.add_argument("--chunks-per-worker", type=int, default=500, help="Chunks per work quantum (default: 500)")
+    # additive
+    p.add_argument("--model-dir", type=str, default=None, help="Directory holding local model folders (sets ARX_MODEL_DIR)")
+    p.add_argument("--out-dtype", type=str, default="float64", choices=["float64", "float32", "float16"],
+                   help="dtype of embeddings.npy (default float64 = the reference's layout)")
+    p.add_argument("--queries", type=str, default=None, help="Text file, one query per line: run the cosine top-k step")
+    p.add_argument("--top-k", type=int, default=10, help="Results per query (default: 10)")
+    p.add_argument("--skip-chroma", action="store_true", help="Do not attempt ChromaDB ingestion")
+    return p
+
+
+def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable] = None) -> int:
+    global _model, _model_name
+    args = build_parser().parse_args(argv)
+    input_dir = Path(args.input_dir)
+    if not input_dir.exists():
+        print(f"Error: Directory {input_dir} not found")
+        return 1
+    if args.model_dir:
+        os.environ["ARX_MODEL_DIR"] = args.model_dir
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            dist.init_process_group(backend)
+    cpu_count = mp.cpu_count()
+    print("=" * 80)
+    print("PARALLEL EMBEDDING GENERATION - MI355X")
+    print("=" * 80)
+    print(f"\nSystem: {cpu_count} CPU cores, {world} GPU rank(s)")
+    print("Configuration:")
+    print(f"  Model: {args.model}")
+    print(f"  Min quality: {args.min_quality}")
+    print(f"  Batch size: {args.batch_size}")
+    print(f"  Load workers: {args.load_workers or int(cpu_count * 0.8)}")
+    print(f"  Store batch size: {args.store_batch_size}")
+    print(f"  ChromaDB: {args.chroma_db}\n")
+    try:
+        t_start = time.time()
+        chunks = load_chunks_parallel(input_dir, min_quality=args.min_quality, num_workers=args.load_workers)
+        if not chunks:
+            print("No chunks found!")
+            return 1
+        load_time = time.time() - t_start
+        print(f"Loading completed in {load_time:.1f} seconds\n")
+        try:
+            _model, _model_name = None, None
+            init_worker_model(args.model, model_factory)
+        except (ImportError, FileNotFoundError, OSError, RuntimeError) as e:
+            print(f"Error: embedding backend not available: {e}")
+            return 1
+        t0 = time.time()
+        embeddings = generate_embeddings_parallel(chunks, model_name=args.model, batch_size=args.batch_size,
+                                                  num_workers=args.embedding_workers, chunks_per_worker=args.chunks_per_worker)
+        embedding_time = time.time() - t0
+        print(f"Embedding generation completed in {embedding_time:.1f} seconds ({embedding_time / 60:.1f} min)\n")
+        if rank == 0:
+            print("Saving embeddings to disk as backup...")
+            save_embeddings_to_disk_fallback(chunks, embeddings, output_dir="./embeddings_saved", out_dtype=args.out_dtype)
+            print()
+        if args.queries:
+            qs = [ln.strip() for ln in Path(args.queries).read_text(encoding="utf-8").splitlines() if ln.strip()]
+            if qs:
+                search_queries(_model, chunks, embeddings, qs, top_k=args.top_k)
+        store_time = 0.0
+        if rank == 0 and not args.skip_chroma:
+            try:
+                import chromadb                                        # noqa: F401
+            except ImportError:
+                print("Error: chromadb not available")
+                print("Install with: pip install chromadb")
+                return 1
+            t0 = time.time()
+            try:
+                store_in_chroma_batched(chunks, embeddings, db_path=args.chroma_db, collection_name=args.collection_name,
+                                        batch_size=args.store_batch_size)
+                store_time = time.time() - t0
+                print(f"Storage completed in {store_time:.1f} seconds")
+            except Exception as e:                                     # noqa: BLE001
+                store_time = time.time() - t0
+                print(f"⚠️  ChromaDB storage failed after {store_time:.1f} seconds: {e}")
+                print("✅ Embeddings are safely saved to ./embeddings_saved/")
+        total = time.time() - t_start
+        print("\n" + "=" * 80)
+        print("EMBEDDING GENERATION COMPLETE")
+        print("=" * 80)
+        print(f"Chunks processed: {len(chunks):,}")
+        print(f"Embeddings generated: {len(embeddings):,}")
+        if len(embeddings):
+            print(f"Embedding dimensions: {len(embeddings[0])}")
+        print(f"Stored in: {args.chroma_db}\n")
+        print("Timing:")
+        print(f"  Loading: {load_time:.1f}s")
+        print(f"  Embedding: {embedding_time:.1f}s ({embedding_time / 60:.1f} min)")
+        print(f"  Storage: {store_time:.1f}s")
+        print(f"  Total: {total:.1f}s ({total / 60:.1f} min)")
+        print("=" * 80)
+        return 0
+    except KeyboardInterrupt:
+        print("\n\n⚠️  Process interrupted by user")
+        return 1
+    except Exception as e:                                             # noqa: BLE001
+        print(f"\n\n❌ Fatal error: {e}")
+        traceback.print_exc()
+        return 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -58,12 +58,25 @@ class ShardIndex:
         s, i = self.search(queries_f16, k)
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return s, i
-        P = dist.get_world_size(group)
-        all_s = torch.empty((P,) + tuple(s.shape), dtype=s.dtype, device=s.device)
-        all_i = torch.empty((P,) + tuple(i.shape), dtype=i.dtype, device=i.device)
-        dist.all_gather_into_tensor(all_s, s, group=group)
-        dist.all_gather_into_tensor(all_i, i, group=group)
+        all_s, all_i = gather_partials(s, i, group)
         return merge_partials(all_s, all_i, k)
+
+
+def gather_partials(s: torch.Tensor, i: torch.Tensor, group=None):
+    """The path's only exchange step: every rank contributes its [Q, k] partial (scores, global ids);
+    returns the stacked [P, Q, k] tensors on every rank (RCCL on GPU tensors, gloo on CPU tensors)."""
+    import torch.distributed as dist
+    P = dist.get_world_size(group)
+    all_s = torch.empty((P,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+    all_i = torch.empty((P,) + tuple(i.shape), dtype=i.dtype, device=i.device)
+    if s.is_cuda:
+        dist.all_gather_into_tensor(all_s, s.contiguous(), group=group)
+        dist.all_gather_into_tensor(all_i, i.contiguous(), group=group)
+    else:                                   # gloo: list form
+        ls = [torch.empty_like(s) for _ in range(P)]; li = [torch.empty_like(i) for _ in range(P)]
+        dist.all_gather(ls, s.contiguous(), group=group); dist.all_gather(li, i.contiguous(), group=group)
+        all_s = torch.stack(ls); all_i = torch.stack(li)
+    return all_s, all_i
 
 
 def merge_partials(all_scores: torch.Tensor, all_ids: torch.Tensor, k: int):

@@ -1,0 +1,275 @@
+"""Host logic on CPU: loader / writer against the reference's own functions' output (tests/golden/harness,
+made by tools/make_golden.py from GEN:76-92 and GEN:271-321), CLI flags/exit codes/order/fallbacks with an
+oracle-backed model injected, tokenizer vs the pure-Python restatement, C-ABI exports, world-size-2 gloo."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from arxiv_rag_amd import config as C
+from arxiv_rag_amd import generate_embeddings_parallel as GEN
+from arxiv_rag_amd.tokenizer import WordPieceTokenizer
+from arxiv_rag_amd.weights import seeded_state_dict
+from oracle import encoder_oracle as EO, tokenizer_oracle as TO
+from tests.helpers import OracleSentenceModel, make_chunk_tree, synthetic_vocab
+
+ROOT = Path(__file__).resolve().parents[1]
+HARN = ROOT / "tests" / "golden" / "harness"
+
+
+# ------------------------------------------------------------------ loader / writer vs the reference's own output
+def test_loader_matches_reference_output():
+    files = sorted(f for f in (HARN / "input").rglob("*.json") if not f.name.startswith("._"))
+    got = []
+    for f in files:
+        got.extend(GEN.load_chunks_from_file(f, min_quality=0.9))
+    assert [c.get("chunk_id") for c in got] == json.loads((HARN / "expected_loaded_ids.json").read_text())
+    allc = GEN.load_chunks_parallel(HARN / "input", min_quality=0.9, num_workers=2)
+    assert [c.get("chunk_id") for c in allc] == [c.get("chunk_id") for c in got]       # ._ file skipped, broken file ignored
+
+
+def test_writer_bytes_match_reference_output(tmp_path):
+    files = sorted(f for f in (HARN / "input").rglob("*.json") if not f.name.startswith("._"))
+    chunks = [c for f in files for c in GEN.load_chunks_from_file(f, 0.9)]
+    embs = list(np.load(HARN / "input_embeddings_f32.npy"))
+    embs[1] = np.zeros(8)                                   # float64 zero-vector fallback row (GEN:169)
+    GEN.save_embeddings_to_disk_fallback(chunks, embs, output_dir=str(tmp_path))
+    for n in ("metadata.json", "index.json", "embeddings.npy"):
+        assert (tmp_path / n).read_bytes() == (HARN / f"expected_{n}").read_bytes(), n
+    meta = json.loads((HARN / "expected_embeddings_meta.json").read_text())
+    arr = np.load(tmp_path / "embeddings.npy")
+    assert str(arr.dtype) == meta["dtype"] == "float64" and list(arr.shape) == meta["shape"]
+    assert hashlib.sha256(arr.tobytes()).hexdigest() == meta["sha256"]
+
+
+def test_cli_flags_and_defaults_match_reference():
+    """flag names and defaults of GEN:471-491 (read from the reference text when it is present)."""
+    p = GEN.build_parser()
+    d = vars(p.parse_args(["some_dir"]))
+    want = {"model": "all-mpnet-base-v2", "min_quality": 0.9, "batch_size": 200, "chroma_db": "./chroma_db",
+            "collection_name": "scientific_papers", "load_workers": None, "embedding_workers": None,
+            "store_batch_size": 2000, "chunks_per_worker": 500}
+    for k, v in want.items():
+        assert d[k] == v, k
+    ref = Path("/root/reference/4-embed/generation/generate_embeddings_parallel.py")
+    if ref.exists():
+        flags = set(re.findall(r"add_argument\('(--[a-z-]+)'", ref.read_text()))
+        ours = {a for act in p._actions for a in act.option_strings}
+        assert flags <= ours, flags - ours
+
+
+# ------------------------------------------------------------------ CLI end to end (cfg-1 style plumbing, scaled to CPU)
+@pytest.fixture()
+def tiny_model():
+    cfg = C.TINY_BERT
+    sd = seeded_state_dict(cfg, seed=4, std=0.05)
+    tok = WordPieceTokenizer.from_vocab(synthetic_vocab(cfg), cfg)
+    return cfg, sd, tok
+
+
+def test_cli_end_to_end_order_layout_and_filter(tmp_path, tiny_model, monkeypatch):
+    cfg, sd, tok = tiny_model
+    chunks = make_chunk_tree(tmp_path / "in", n_files=10, chunks_per_file=6)
+    monkeypatch.chdir(tmp_path)
+    model = OracleSentenceModel(cfg, sd, tok)
+    rc = GEN.main([str(tmp_path / "in"), "--model", "tiny-bert", "--batch-size", "7", "--chunks-per-worker", "16",
+                   "--min-quality", "0.9", "--skip-chroma"], model_factory=lambda name: model)
+    assert rc == 0
+    kept = GEN.load_chunks_parallel(tmp_path / "in", 0.9, 2)
+    assert 0 < len(kept) < len(chunks) and all(c["metadata"]["quality_score"] >= 0.9 for c in kept)
+    arr = np.load(tmp_path / "embeddings_saved" / "embeddings.npy")
+    assert arr.dtype == np.float64 and arr.shape == (len(kept), cfg.hidden) and not np.isfortran(arr)
+    meta = json.loads((tmp_path / "embeddings_saved" / "metadata.json").read_text())
+    assert [m["chunk_id"] for m in meta] == [c["chunk_id"] for c in kept]
+    assert list(meta[0].keys()) == ["chunk_id", "paper_id", "section", "quality_score", "text", "text_length"]
+    idx = json.loads((tmp_path / "embeddings_saved" / "index.json").read_text())
+    assert idx == {"total_embeddings": len(kept), "embedding_dimension": cfg.hidden, "total_size_gb": arr.nbytes / 2**30}
+    # row i <-> chunk i, independent of the quantum / sub-batch split
+    ref = EO.encode_ragged(sd, cfg, tok.encode_batch([c["text"] for c in kept], cfg.max_seq_length), batch_size=64)
+    cos = (arr * ref).sum(1) / (np.linalg.norm(arr, axis=1) * np.linalg.norm(ref, axis=1))
+    assert cos.min() > 1 - 1e-6
+    assert max(model.calls) <= 7                           # sub-batches honour --batch-size
+
+
+def test_cli_exit_codes(tmp_path, tiny_model, monkeypatch):
+    cfg, sd, tok = tiny_model
+    monkeypatch.chdir(tmp_path)
+    assert GEN.main([str(tmp_path / "missing")]) == 1                                   # GEN:497-499
+    (tmp_path / "empty").mkdir()
+    assert GEN.main([str(tmp_path / "empty"), "--skip-chroma"], model_factory=lambda n: None) == 1   # GEN:527-529
+    make_chunk_tree(tmp_path / "in", n_files=2, chunks_per_file=3)
+    def boom(name):
+        raise FileNotFoundError("no local model")
+    assert GEN.main([str(tmp_path / "in"), "--min-quality", "0.0", "--skip-chroma"], model_factory=boom) == 1
+    # chromadb absent -> 1 AFTER the disk backup was written (GEN:553-562)
+    model = OracleSentenceModel(cfg, sd, tok)
+    rc = GEN.main([str(tmp_path / "in"), "--min-quality", "0.0"], model_factory=lambda n: model)
+    try:
+        import chromadb  # noqa: F401
+        assert rc == 0
+    except ImportError:
+        assert rc == 1
+    assert (tmp_path / "embeddings_saved" / "embeddings.npy").exists()
+
+
+def test_worker_fallbacks_never_raise(tiny_model):
+    """batch failure -> per-item retry -> zero row (GEN:155-169); whole-quantum failure -> error tuple (172-177)."""
+    cfg, sd, tok = tiny_model
+    texts = ["alpha beta", "POISON gamma", "delta", "epsilon zeta"]
+    model = OracleSentenceModel(cfg, sd, tok, fail_on=lambda s: any("POISON" in t for t in s))
+    GEN._model, GEN._model_name = model, "m"
+    idx, rows, err = GEN.generate_embeddings_worker((texts, "m", 4, 3))
+    assert idx == 3 and err is None and len(rows) == 4
+    assert np.array_equal(rows[1], np.zeros(cfg.hidden)) and rows[1].dtype == np.float64
+    ok = EO.encode_ragged(sd, cfg, tok.encode_batch([texts[0]], cfg.max_seq_length))
+    assert np.allclose(rows[0], ok[0], atol=1e-6)
+    GEN._model = None; GEN._model_name = None
+    def boom(name):
+        raise RuntimeError("cannot load")
+    import arxiv_rag_amd.generate_embeddings_parallel as G2
+    orig = G2.get_worker_model
+    G2.get_worker_model = boom
+    try:
+        idx, rows, err = G2.generate_embeddings_worker((texts, "m", 4, 9))
+    finally:
+        G2.get_worker_model = orig
+    assert idx == 9 and rows == [] and "cannot load" in err
+
+
+def test_missing_quantum_is_padded_with_zero_rows(tiny_model, monkeypatch):
+    cfg, sd, tok = tiny_model
+    chunks = [{"text": f"alpha {i}", "metadata": {}} for i in range(10)]
+    model = OracleSentenceModel(cfg, sd, tok)
+    GEN._model, GEN._model_name = model, "m"
+    real = GEN.generate_embeddings_worker
+    monkeypatch.setattr(GEN, "generate_embeddings_worker", lambda a: (a[3], [], "dead") if a[3] == 1 else real(a))
+    embs = GEN.generate_embeddings_parallel(chunks, "m", batch_size=4, chunks_per_worker=4)
+    assert len(embs) == 10
+    assert all(np.array_equal(e, np.zeros(cfg.hidden)) for e in embs[-4:])               # padded at the end, as GEN:260-265
+    GEN._model = None
+
+
+# ------------------------------------------------------------------ tokenizer
+@pytest.mark.parametrize("preset", ["tiny-mpnet", "tiny-bert"])
+def test_tokenizer_matches_python_restatement(preset):
+    cfg = C.PRESETS[preset]
+    vocab = synthetic_vocab(cfg)
+    tok = WordPieceTokenizer.from_vocab(vocab, cfg)
+    rs = np.random.RandomState(0)
+    words = [w for w in vocab if w.isalpha() and len(w) > 1][:40]
+    texts = ["", "   ", "Alpha,beta!  (Gamma)", "Über-naïve café\tx y", "x" * 150 + " ok", "日本 ab"]
+    for _ in range(60):
+        n = rs.randint(1, 90)
+        texts.append(" ".join(rs.choice(words + ["zzzzqq", "A.B", "c-d"], size=n)))
+    got = tok.encode_batch(texts, 64)
+    for t, g in zip(texts, got):
+        assert g == TO.encode(t, vocab, cfg.arch == C.ARCH_MPNET, 64), t
+        assert len(g) <= 64 and len(g) >= 2
+
+
+def test_tokenizer_from_dir_vocab_txt(tmp_path):
+    cfg = C.TINY_BERT
+    vocab = synthetic_vocab(cfg)
+    (tmp_path / "vocab.txt").write_text("\n".join(sorted(vocab, key=vocab.get)) + "\n", encoding="utf-8")
+    a = WordPieceTokenizer.from_dir(tmp_path, cfg).encode_batch(["alpha beta, gamma"], 32)
+    b = WordPieceTokenizer.from_vocab(vocab, cfg).encode_batch(["alpha beta, gamma"], 32)
+    assert a == b
+
+
+# ------------------------------------------------------------------ C ABI
+def test_cabi_exports_every_declared_symbol():
+    from arxiv_rag_amd import _lib
+    hdr = (ROOT / "include" / "arx.h").read_text()
+    declared = set(re.findall(r"\b(arx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert _lib.LIB_PATH.exists(), "libarx_hip.so not built (run __graft_entry__.build())"
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/arx.h but not exported"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    bound = _lib.load()
+    assert bound.arx_version() == 100
+    # host-only entry point: MPNet bucket table vs the golden (transformers) values — no GPU involved
+    g = np.load(ROOT / "tests" / "golden" / "mpnet_tables.npz")
+    got = np.array([bound.arx_mpnet_bucket(int(d), 32, 128) for d in g["delta"]])
+    assert np.array_equal(got, g["bucket_of_delta"])
+    assert bound.arx_topk_workspace_bytes(10_000_000, 256, 768, 10) > 0
+    assert bound.arx_topk_workspace_bytes(10, 1, 768, 99) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from arxiv_rag_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(_lib.ArxError):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    for f in list((ROOT / "arxiv_rag_amd").glob("*.py")) + [ROOT / "arxiv_rag_amd" / "csrc" / "build.sh"]:
+        assert not re.search(r"^\s*(from|import)\s+(oracle|tests)\b", f.read_text(), re.M), f
+
+
+# ------------------------------------------------------------------ world size 2 (gloo, CPU)
+_WORKER = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ["ARX_ROOT"])
+import torch, torch.distributed as dist
+from arxiv_rag_amd import config as C, generate_embeddings_parallel as GEN
+from arxiv_rag_amd.index import gather_partials, shard_bounds
+from arxiv_rag_amd.tokenizer import WordPieceTokenizer
+from arxiv_rag_amd.weights import seeded_state_dict
+from oracle import search_oracle as SO
+from tests.helpers import OracleSentenceModel, synthetic_vocab
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+cfg = C.TINY_BERT
+model = OracleSentenceModel(cfg, seeded_state_dict(cfg, seed=4, std=0.05), WordPieceTokenizer.from_vocab(synthetic_vocab(cfg), cfg))
+os.chdir(os.environ["ARX_OUT"])
+rc = GEN.main([os.environ["ARX_IN"], "--model", "tiny-bert", "--batch-size", "5", "--chunks-per-worker", "7",
+               "--min-quality", "0.0", "--skip-chroma"], model_factory=lambda n: model)
+assert rc == 0
+# the search exchange step: local partial top-k (oracle as the stand-in for the HIP kernel) -> all_gather -> merge
+Cm = SO.unit_rows_f16(1001, 64, 1); Q = SO.unit_rows_f16(9, 64, 2)
+lo, hi = shard_bounds(1001, world, rank)
+s, i = SO.topk_search(Cm[lo:hi], Q, 10, idx_base=lo)
+all_s, all_i = gather_partials(torch.from_numpy(s), torch.from_numpy(i))
+ms, mi = SO.merge_partials(all_s.numpy(), all_i.numpy(), 10)
+gs, gi = SO.topk_search(Cm, Q, 10)
+assert np.array_equal(mi, gi) and np.array_equal(ms, gs)
+dist.barrier()
+if rank == 0:
+    print("WORKER_OK", sum(model.calls))
+dist.destroy_process_group()
+'''
+
+
+def test_world_size_2_gloo_matches_single_process(tmp_path, tiny_model):
+    cfg, sd, tok = tiny_model
+    make_chunk_tree(tmp_path / "in", n_files=6, chunks_per_file=5)
+    (tmp_path / "w.py").write_text(_WORKER)
+    (tmp_path / "out2").mkdir(); (tmp_path / "out1").mkdir()
+    env = dict(os.environ, ARX_ROOT=str(ROOT), ARX_IN=str(tmp_path / "in"), ARX_OUT=str(tmp_path / "out2"),
+               OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(tmp_path / "w.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    cwd = os.getcwd()
+    os.chdir(tmp_path / "out1")
+    try:
+        model = OracleSentenceModel(cfg, sd, tok)
+        assert GEN.main([str(tmp_path / "in"), "--model", "tiny-bert", "--batch-size", "5", "--chunks-per-worker", "7",
+                         "--min-quality", "0.0", "--skip-chroma"], model_factory=lambda n: model) == 0
+    finally:
+        os.chdir(cwd)
+    for n in ("embeddings.npy", "metadata.json", "index.json"):
+        assert (tmp_path / "out1" / "embeddings_saved" / n).read_bytes() == (tmp_path / "out2" / "embeddings_saved" / n).read_bytes(), n
