@@ -37,7 +37,8 @@ struct arx_encoder {
     float* bias_tbl = nullptr;
     uint16_t* tap = nullptr;
     int tap_layer = -1;
-    bool glds = true;
+    int variant = 13;
+    int attn_variant = 1;
 };
 
 struct WsLayout {
@@ -100,8 +101,12 @@ extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_e
     h->max_tokens = max_tokens;
     h->max_seqs = max_seqs;
     h->tok_pad = (int)round_up64(max_tokens, 256);
-    const char* e = getenv("ARX_GEMM_GLDS");
-    h->glds = !(e && e[0] == '0');
+    const char* e = getenv("ARX_GEMM_VARIANT");
+    h->variant = e ? atoi(e) : 13;
+    const char* av = getenv("ARX_ATTN_VARIANT");
+    h->attn_variant = av ? atoi(av) : 1;
+    const char* g = getenv("ARX_GEMM_GLDS");          // legacy switch: 0 = register-staged reference loop
+    if (g && g[0] == '0') h->variant = 4;
     const WsLayout l = ws_layout(*cfg, max_tokens, max_seqs);
     hipError_t he = hipMalloc((void**)&h->ws, l.total);
     if (he != hipSuccess) {
@@ -174,37 +179,98 @@ extern "C" int32_t arx_encoder_debug_hidden(arx_encoder* h, int32_t /*layer_slot
 }
 
 // ---- GEMM dispatch ------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool GLDS, int MODE>
-static int launch_gemm_cfg(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int N, int K,
-                           const EpiParams& ep, hipStream_t st) {
-    using ML = GemmMainloop<bf16_t, BM, BN, WM, WN, GLDS>;
-    auto kern = gemm_bf16_kernel<BM, BN, WM, WN, GLDS, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ML::SMEM_BYTES));
-        attr_set = true;
+// variant: 0 = 2-stage loop + 8-B stores (round-1 first version), 1 = 2-stage loop + 16-B/64-B-segment epilogue,
+//          2 = ring 256x128 (4 waves, 3 half-tile slots, 2 blocks/CU), 3 = ring 256x256 (8 waves, 4 slots)
+template <typename Kern>
+static int launch_gemm_kernel(Kern kern, int smem, int threads, int BM, int BN, const uint16_t* A, int64_t lda,
+                              const uint16_t* W, int64_t ldw, int M, int N, int K, const EpiParams& ep, hipStream_t st,
+                              bool* attr_set) {
+    if (!*attr_set) {
+        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        *attr_set = true;
     }
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
-    kern<<<tm * tn, ML::NT, ML::SMEM_BYTES, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
+    kern<<<tm * tn, threads, smem, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
 
 template <int MODE>
-static int launch_gemm(int cls, bool glds, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int N, int K,
-                       const EpiParams& ep, hipStream_t st) {
-    if (K % 64 != 0 || N % 4 != 0) {
-        arx_set_error("gemm: K=%d must be a multiple of 64 and N=%d of 4", K, N);
+int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int N, int K,
+                    const EpiParams& ep, hipStream_t st) {
+    if (K % 64 != 0 || N % 8 != 0) {
+        arx_set_error("gemm: K=%d must be a multiple of 64 and N=%d of 8", K, N);
         return ARX_ERR_ARG;
     }
     const bool wide = (N % 256 == 0);
-    ProfScope ps(cls, st);
-    if (glds) {
-        return wide ? launch_gemm_cfg<256, 256, 2, 4, true, MODE>(A, lda, W, ldw, M, N, K, ep, st)
-                    : launch_gemm_cfg<256, 128, 4, 2, true, MODE>(A, lda, W, ldw, M, N, K, ep, st);
+    static bool a0 = false, a1 = false, a2 = false, a3 = false, a4 = false, a5 = false, a6 = false, a7 = false;
+    switch (variant) {
+    case 0:
+        if (wide) return launch_gemm_kernel(gemm_bf16_kernel<256, 256, 2, 4, true, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, true>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a0);
+        return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, true, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, true>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a1);
+    case 4:   // register-staged reference loop (no global_load_lds)
+        if (wide) return launch_gemm_kernel(gemm_bf16_kernel<256, 256, 2, 4, false, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, false>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a6);
+        return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, false, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, false>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a7);
+    case 1:
+        if (wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, true>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a2);
+        { static bool a3b = false;
+        return launch_gemm_kernel(gemm_v0e2_kernel<256, 128, 4, 2, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, true>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a3b); }
+#define ARX_EXP_CASE(ID, OPT)                                                                                          \
+    case ID: {                                                                                                         \
+        static bool ax = false;                                                                                        \
+        return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, OPT>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, OPT>::SMEM_BYTES, \
+                                  512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &ax);                                \
     }
-    return wide ? launch_gemm_cfg<256, 256, 2, 4, false, MODE>(A, lda, W, ldw, M, N, K, ep, st)
-                : launch_gemm_cfg<256, 128, 4, 2, false, MODE>(A, lda, W, ldw, M, N, K, ep, st);
+    ARX_EXP_CASE(11, 1)
+    ARX_EXP_CASE(12, 2)
+    case 13:      // default: 2-stage loop, upper-half waves issue loads mid-step, setprio around MFMA clusters,
+                  // k-loop start rotated by 2*tile_n (blocks sharing an A panel do not miss on the same lines at once)
+        if (!wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 128, 4, 2, MODE, 67>, GemmMainloop<bf16_t, 256, 128, 4, 2, true, 67>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a3);
+        {
+            static bool ax13 = false;
+            return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 67>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 67>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &ax13);
+        }
+    ARX_EXP_CASE(15, 3)
+    ARX_EXP_CASE(14, 4)
+    ARX_EXP_CASE(18, 8 + 3)
+    ARX_EXP_CASE(19, 8 + 3 + 16)
+    ARX_EXP_CASE(20, 8 + 3 + 32)
+    ARX_EXP_CASE(21, 3 + 16)
+    ARX_EXP_CASE(22, 3 + 64)
+    ARX_EXP_CASE(23, 3 + 128)
+    ARX_EXP_CASE(24, 3 + 256)
+    case 3:
+        if (wide) return launch_gemm_kernel(gemm_ring_kernel<256, 256, 2, 4, 4, MODE>, GemmRing<bf16_t, 256, 256, 2, 4, 4>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a4);
+        [[fallthrough]];
+    case 2:
+    default:
+        return launch_gemm_kernel(gemm_ring_kernel<256, 128, 2, 2, 3, MODE>, GemmRing<bf16_t, 256, 128, 2, 2, 3>::SMEM_BYTES, 256, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a5);
+    }
+}
+
+template <int MODE>
+static int launch_gemm(int cls, int variant, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int N, int K,
+                       const EpiParams& ep, hipStream_t st) {
+    ProfScope ps(cls, st);
+    return arx_launch_gemm<MODE>(variant, A, lda, W, ldw, M, N, K, ep, st);
+}
+
+// Raw linear layer C = epi(A W^T + bias [+ resid]) — building block exposed for unit tests / tuning.
+extern "C" int32_t arx_gemm_bf16(const void* A, const void* W, const float* bias, const void* resid, void* C, int32_t M,
+                                 int32_t N, int32_t K, int32_t mode, int32_t variant, void* stream) {
+    ARX_REQUIRE(A && W && bias && C, "null pointer argument");
+    ARX_REQUIRE(M > 0 && N > 0 && K > 0, "bad sizes");
+    ARX_REQUIRE(mode != EPI_BIAS_RESID || resid, "mode 2 needs resid");
+    EpiParams ep{(uint16_t*)C, N, bias, (const uint16_t*)resid, N};
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps(ARX_K_GEMM_FC1, st);
+    switch (mode) {
+    case EPI_BIAS: return arx_launch_gemm<EPI_BIAS>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
+    case EPI_BIAS_GELU: return arx_launch_gemm<EPI_BIAS_GELU>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
+    case EPI_BIAS_RESID: return arx_launch_gemm<EPI_BIAS_RESID>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
+    }
+    arx_set_error("unknown gemm mode %d", mode);
+    return ARX_ERR_ARG;
 }
 
 // ---- attention dispatch -------------------------------------------------------------------------
@@ -226,9 +292,36 @@ static int launch_attn_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream_t 
     return ARX_OK;
 }
 
+template <int DH, bool HB, int NW>
+static int launch_attn_tr_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
+    auto kern = attention_tr_kernel<DH, HB, NW>;
+    const int Lk = (max_len + 31) & ~31;
+    const int smem = AttnSmem2<DH>::total(Lk, HB);
+    static int attr_max = 0;
+    if (smem > attr_max) {
+        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_max = smem;
+    }
+    const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
+    dim3 grid(cdiv(max_len, 32 * NW), h->cfg.heads, n_seqs);
+    ProfScope ps(ARX_K_ATTENTION, st);
+    kern<<<grid, NW * 64, smem, st>>>(h->qkv, h->ctx, h->cu, h->bias_tbl, h->cfg.hidden, scale_log2e);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
 static int launch_attn(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
     const int dh = h->cfg.hidden / h->cfg.heads;
     const bool hb = h->cfg.arch == ARX_ARCH_MPNET;
+    if (h->attn_variant == 1) {      // transposing-read kernel; 8 waves cover 256 queries, 4 waves for short batches
+        const bool w8 = max_len > 128;
+        if (dh == 64) {
+            if (hb) return w8 ? launch_attn_tr_cfg<64, true, 8>(h, n_seqs, max_len, st) : launch_attn_tr_cfg<64, true, 4>(h, n_seqs, max_len, st);
+            return w8 ? launch_attn_tr_cfg<64, false, 8>(h, n_seqs, max_len, st) : launch_attn_tr_cfg<64, false, 4>(h, n_seqs, max_len, st);
+        }
+        if (hb) return w8 ? launch_attn_tr_cfg<32, true, 8>(h, n_seqs, max_len, st) : launch_attn_tr_cfg<32, true, 4>(h, n_seqs, max_len, st);
+        return w8 ? launch_attn_tr_cfg<32, false, 8>(h, n_seqs, max_len, st) : launch_attn_tr_cfg<32, false, 4>(h, n_seqs, max_len, st);
+    }
     const bool big = max_len > 256;     // > 80 KB of LDS per block anyway: use 8 waves per block
     if (dh == 64) {
         if (hb) return big ? launch_attn_cfg<64, true, 8>(h, n_seqs, max_len, st) : launch_attn_cfg<64, true, 4>(h, n_seqs, max_len, st);
@@ -284,19 +377,19 @@ extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32
         EpiParams ep;
         // qkv = x Wqkv^T + b
         ep = EpiParams{h->qkv, 3 * (int64_t)H, L.b_qkv, nullptr, 0};
-        if ((rc = launch_gemm<EPI_BIAS>(ARX_K_GEMM_QKV, h->glds, h->x, H, (const uint16_t*)L.w_qkv, H, T, 3 * H, H, ep, st)) != ARX_OK) return rc;
+        if ((rc = launch_gemm<EPI_BIAS>(ARX_K_GEMM_QKV, h->variant, h->x, H, (const uint16_t*)L.w_qkv, H, T, 3 * H, H, ep, st)) != ARX_OK) return rc;
         if ((rc = launch_attn(h, n_seqs, max_len, st)) != ARX_OK) return rc;
         // y = ctx Wo^T + b + x ; x1 = LN(y)
         ep = EpiParams{h->y, H, L.b_o, h->x, H};
-        if ((rc = launch_gemm<EPI_BIAS_RESID>(ARX_K_GEMM_OPROJ, h->glds, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st)) != ARX_OK) return rc;
+        if ((rc = launch_gemm<EPI_BIAS_RESID>(ARX_K_GEMM_OPROJ, h->variant, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st)) != ARX_OK) return rc;
         { ProfScope ps(ARX_K_LAYERNORM, st);
         layernorm_kernel<<<ln_grid, 256, 0, st>>>(h->y, h->x1, L.ln1_g, L.ln1_b, h->cu + n_seqs, H, c.ln_eps); }
         ARX_HIP_CHECK(hipGetLastError());
         // hbuf = gelu(x1 W1^T + b1) ; y = hbuf W2^T + b2 + x1 ; x = LN(y)
         ep = EpiParams{h->hbuf, F, L.b_fc1, nullptr, 0};
-        if ((rc = launch_gemm<EPI_BIAS_GELU>(ARX_K_GEMM_FC1, h->glds, h->x1, H, (const uint16_t*)L.w_fc1, H, T, F, H, ep, st)) != ARX_OK) return rc;
+        if ((rc = launch_gemm<EPI_BIAS_GELU>(ARX_K_GEMM_FC1, h->variant, h->x1, H, (const uint16_t*)L.w_fc1, H, T, F, H, ep, st)) != ARX_OK) return rc;
         ep = EpiParams{h->y, H, L.b_fc2, h->x1, H};
-        if ((rc = launch_gemm<EPI_BIAS_RESID>(ARX_K_GEMM_FC2, h->glds, h->hbuf, F, (const uint16_t*)L.w_fc2, F, T, H, F, ep, st)) != ARX_OK) return rc;
+        if ((rc = launch_gemm<EPI_BIAS_RESID>(ARX_K_GEMM_FC2, h->variant, h->hbuf, F, (const uint16_t*)L.w_fc2, F, T, H, F, ep, st)) != ARX_OK) return rc;
         { ProfScope ps(ARX_K_LAYERNORM, st);
         layernorm_kernel<<<ln_grid, 256, 0, st>>>(h->y, h->x, L.ln2_g, L.ln2_b, h->cu + n_seqs, H, c.ln_eps); }
         ARX_HIP_CHECK(hipGetLastError());

@@ -334,6 +334,178 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------------
+// attention v2: same algorithm, but
+//   * V is staged ROW-major (16-B ds_write_b128, chunk XOR 4*((row>>1)&1) for DH = 64) and the V^T MFMA operand
+//     is produced by the hardware transposing read ds_read_b64_tr_b16 (two per k-step: keys 16s+4hh.. and
+//     16s+8+4hh.. at this lane's dh column) — no b16 scatter while staging;
+//   * NW = 8 waves x 32 queries: one block covers a whole 256-token sequence-head, K/V staged once;
+//   * the key mask is applied only in the (uniform) ragged last tile; O is rescaled only when some lane's
+//     running max moved.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int DH> struct AttnSmem2 {
+    static __host__ __device__ int kv_bytes(int Lk) { return Lk * DH * 2; }
+    static __host__ __device__ int bias_stride(int Lk) { return 2 * Lk + 8; }
+    static __host__ __device__ int total(int Lk, bool has) { return 2 * kv_bytes(Lk) + (has ? 4 * (2 * Lk + 8) * 4 : 0); }
+};
+
+template <int DH, bool HAS_BIAS, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
+                                                                        const int32_t* __restrict__ cu,
+                                                                        const float* __restrict__ bias_tbl, int H,
+                                                                        float scale_log2e) {
+    constexpr int NT = NW * 64;
+    constexpr int CPR = DH / 8;
+    constexpr int RPB = 256 / (DH * 2);
+    constexpr int KS = DH / 16;
+    constexpr int DB = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int t0 = cu[b];
+    const int L = cu[b + 1] - t0;
+    const int q0 = blockIdx.x * (32 * NW);
+    if (q0 >= L) return;
+    const int Lk = (L + 31) & ~31;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t ld = 3 * (int64_t)H;
+    const uint16_t* Qg = qkv + (int64_t)t0 * ld + h * DH;
+    const uint16_t* Kg = Qg + H;
+    const uint16_t* Vg = Qg + 2 * H;
+    char* Ks = smem;
+    char* Vs = smem + AttnSmem2<DH>::kv_bytes(Lk);
+    float* Bs = reinterpret_cast<float*>(smem + 2 * AttnSmem2<DH>::kv_bytes(Lk));
+    const int bst = AttnSmem2<DH>::bias_stride(Lk);
+
+    for (int cid = tid; cid < Lk * CPR; cid += NT) {
+        const int row = cid / CPR, pc = cid % CPR;
+        const int kc = pc ^ ((row / RPB) & (CPR - 1));
+        const int vc = (DH == 64) ? (pc ^ (((row >> 1) & 1) << 2)) : pc;
+        u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
+        if (row < L) {
+            kv = *reinterpret_cast<const u32x4*>(Kg + (int64_t)row * ld + kc * 8);
+            vv = *reinterpret_cast<const u32x4*>(Vg + (int64_t)row * ld + vc * 8);
+        }
+        *reinterpret_cast<u32x4*>(Ks + (int64_t)cid * 16) = kv;
+        *reinterpret_cast<u32x4*>(Vs + (int64_t)cid * 16) = vv;
+    }
+    if (HAS_BIAS) {
+        const float* bt = bias_tbl + (int64_t)h * ARX_BIAS_ROW + ARX_BIAS_CENTER;
+        for (int i = tid; i < 4 * bst; i += NT) {
+            const int c = i / bst, j = i % bst;
+            int d = j + c - Lk;
+            d = d < -ARX_BIAS_CENTER ? -ARX_BIAS_CENTER : (d > ARX_BIAS_CENTER ? ARX_BIAS_CENTER : d);
+            Bs[i] = bt[d];
+        }
+    }
+    __syncthreads();
+
+    const int qw = q0 + wid * 32;
+    if (qw >= L) return;
+    const int ql = lane & 31, hh = lane >> 5;
+    const int q = qw + ql;
+    const int qc = q < L ? q : L - 1;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)qc * ld + ks * 16 + hh * 8);
+    f32x16 o[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int bc = (4 - (qc & 3)) & 3;
+    const float* brow = Bs + bc * bst + (Lk - qc - bc);
+    const int krow_sw = ((ql / RPB) & (CPR - 1));
+    // transposing-read lane constants: 16-lane group g16, lane i in group: row q_ = i>>2, column quad p = i&3
+    const int g16 = lane >> 4, q_ = (lane & 15) >> 2, p_ = lane & 3;
+    const int vsw = (DH == 64) ? (((q_ >> 1) & 1) << 2) : 0;
+    int voff[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+        const int col = 32 * d + 16 * (g16 & 1) + 4 * p_;                 // dh of this lane's 4-element run
+        voff[d] = (4 * hh + q_) * (DH * 2) + (((col >> 3) ^ vsw) << 4) + ((p_ & 1) << 3);
+    }
+    const int nkt = Lk >> 5;
+    const bool ragged = (L & 31) != 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const char* krow = Ks + (int64_t)(kt * 32 + ql) * (DH * 2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((2 * ks + hh) ^ krow_sw) << 4));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+        }
+        const bool mask_tile = ragged && (kt == nkt - 1);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int kb = kt * 32 + 8 * g4 + 4 * hh;
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (HAS_BIAS) bv = *reinterpret_cast<const f32x4*>(brow + kb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = fmaf(s[g4 * 4 + e], scale_log2e, bv[e]);
+                if (mask_tile) v = (kb + e < L) ? v : -INFINITY;
+                s[g4 * 4 + e] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            m_run = m_new;
+        }
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_run); rs += s[r]; }
+        l_run += rs;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[ss][e] = (bf16_t)s[8 * ss + e];
+        const char* vtile = Vs + (int64_t)(kt * 32) * (DH * 2);
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vtile + voff[d] + (16 * ss) * (DH * 2)));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vtile + voff[d] + (16 * ss + 8) * (DH * 2)));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                s16x8 v8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v8[e] = lo[e]; v8[4 + e] = hi[e]; }
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, v8);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ss], o[d], 0, 0, 0);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (q < L) {
+        uint16_t* orow = ctx + (int64_t)(t0 + q) * H + h * DH;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                u32x2 w2;
+                w2[0] = pack_bf16x2(o[d][g4 * 4 + 0] * inv, o[d][g4 * 4 + 1] * inv);
+                w2[1] = pack_bf16x2(o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv);
+                *reinterpret_cast<u32x2*>(orow + d * 32 + 8 * g4 + 4 * hh) = w2;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Pool (masked mean over the sequence's tokens, or CLS row) + optional L2 normalise.
 // One block (256 thr) per sequence; writes f32 and/or fp16 rows.
 __global__ __launch_bounds__(256) void pool_norm_kernel(const uint16_t* __restrict__ x, const int32_t* __restrict__ cu,

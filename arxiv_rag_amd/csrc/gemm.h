@@ -31,7 +31,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 // Stage a [ROWS x 64-element] tile (rows row0.., columns k0..k0+63 of G[ld]) into `tile` (LDS).
-template <int ROWS, int NT, bool GLDS>
+template <int ROWS, int NT, bool GLDS, int XOPT = 0>
 __device__ __forceinline__ void stage_issue(const uint16_t* __restrict__ G, int64_t ld, int row0, int row_max,
                                             int k0, char* tile, int tid, u32x4 (&regs)[ROWS * 8 / NT]) {
     constexpr int IT = ROWS * 8 / NT;
@@ -40,9 +40,10 @@ __device__ __forceinline__ void stage_issue(const uint16_t* __restrict__ G, int6
     for (int it = 0; it < IT; ++it) {
         const int cid = it * NT + tid;
         const int row = cid >> 3, pc = cid & 7;
-        const int c = pc ^ ((row >> 1) & 7);
+        const int c = (XOPT & 32) ? pc : (pc ^ ((row >> 1) & 7));
         int grow = row0 + row;
         grow = grow < row_max ? grow : row_max;
+        if constexpr (XOPT & 16) grow &= 1023;          // ABLATION: all tiles read the same 1024 rows (cache-resident)
         const uint16_t* src = G + (int64_t)grow * ld + k0 + c * 8;
         if constexpr (GLDS) {
             char* dst = tile + (it * NT + (tid & ~63)) * 16;      // wave-uniform base; lane l lands at +16*l
@@ -61,7 +62,10 @@ __device__ __forceinline__ void stage_commit(char* tile, int tid, const u32x4 (&
 
 // Main loop: fills acc[NI][MI] for the block tile at (m0, n0).
 //   acc[j][i][r]:  n = n0 + wn*TN + j*16 + (lane>>4)*4 + r ,  m = m0 + wm*TM + i*16 + (lane&15)
-template <typename T, int BM, int BN, int WM, int WN, bool GLDS>
+// OPT bits (experiments): 1 = waves in the upper half issue next-stage loads mid-step (stagger),
+//   2 = s_setprio(1) around MFMA clusters, 4 = ABLATION no global loads after the prologue,
+//   8 = ABLATION no MFMA (fragments kept alive)
+template <typename T, int BM, int BN, int WM, int WN, bool GLDS, int OPT = 0>
 struct GemmMainloop {
     static constexpr int NT = WM * WN * 64;
     static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -71,7 +75,7 @@ struct GemmMainloop {
 
     static __device__ __forceinline__ void run(const T* __restrict__ A, int64_t lda, int M,
                                                const T* __restrict__ W, int64_t ldw, int N, int K,
-                                               int m0, int n0, char* smem, f32x4 (&acc)[NI][MI]) {
+                                               int m0, int n0, char* smem, f32x4 (&acc)[NI][MI], int koff = 0) {
         const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
         const int wm = wid / WN, wn = wid % WN;
         const uint16_t* Ag = reinterpret_cast<const uint16_t*>(A);
@@ -89,8 +93,12 @@ struct GemmMainloop {
 
         u32x4 ra[BM * 8 / NT], rw[BN * 8 / NT];
         const int nk = K >> 6;
-        stage_issue<BM, NT, GLDS>(Ag, lda, m0, M - 1, 0, smem, tid, ra);
-        stage_issue<BN, NT, GLDS>(Wg, ldw, n0, N - 1, 0, smem + A_BYTES, tid, rw);
+        // the k-steps may be visited in any rotation (the sum is order-free up to fp32 rounding): blocks that
+        // share an A panel start at different k so that they do not all miss on the same lines at once
+        koff = koff % nk;
+        auto kstep = [&](int kt) { int k = kt + koff; return (k >= nk ? k - nk : k) << 6; };
+        stage_issue<BM, NT, GLDS, OPT>(Ag, lda, m0, M - 1, kstep(0), smem, tid, ra);
+        stage_issue<BN, NT, GLDS, (OPT & ~16)>(Wg, ldw, n0, N - 1, kstep(0), smem + A_BYTES, tid, rw);
         if constexpr (!GLDS) {
             stage_commit<BM, NT>(smem, tid, ra);
             stage_commit<BN, NT>(smem + A_BYTES, tid, rw);
@@ -99,9 +107,10 @@ struct GemmMainloop {
         for (int kt = 0; kt < nk; ++kt) {
             char* cur = smem + (kt & 1) * STAGE_BYTES;
             char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
-            if (kt + 1 < nk) {
-                stage_issue<BM, NT, GLDS>(Ag, lda, m0, M - 1, (kt + 1) << 6, nxt, tid, ra);
-                stage_issue<BN, NT, GLDS>(Wg, ldw, n0, N - 1, (kt + 1) << 6, nxt + A_BYTES, tid, rw);
+            const bool late = (OPT & 1) && (__builtin_amdgcn_readfirstlane(wid) >= (WM * WN) / 2);
+            if (kt + 1 < nk && !(OPT & 4) && !late) {
+                stage_issue<BM, NT, GLDS, OPT>(Ag, lda, m0, M - 1, kstep(kt + 1), nxt, tid, ra);
+                stage_issue<BN, NT, GLDS, (OPT & ~16)>(Wg, ldw, n0, N - 1, kstep(kt + 1), nxt + A_BYTES, tid, rw);
             }
             const char* As = cur + a_base;
             const char* Ws = cur + A_BYTES + w_base;
@@ -113,10 +122,23 @@ struct GemmMainloop {
                 for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec*>(As + i * 2048 + off);
 #pragma unroll
                 for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const vec*>(Ws + j * 2048 + off);
+                if constexpr (OPT & 8) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
+                    for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<T>::mma(wf[j], af[i], acc[j][i]);
+                    for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(wf[j]));
+                } else {
+                    if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<T>::mma(wf[j], af[i], acc[j][i]);
+                    if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(0);
+                }
+                if (ks == 0 && late && kt + 1 < nk && !(OPT & 4)) {
+                    stage_issue<BM, NT, GLDS, OPT>(Ag, lda, m0, M - 1, kstep(kt + 1), nxt, tid, ra);
+                    stage_issue<BN, NT, GLDS, (OPT & ~16)>(Wg, ldw, n0, N - 1, kstep(kt + 1), nxt + A_BYTES, tid, rw);
+                }
             }
             if constexpr (!GLDS) {
                 if (kt + 1 < nk) {
@@ -187,4 +209,191 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(const bf16_t* _
     ML::run(A, lda, M, W, ldw, N, K, m0, n0, smem, acc);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     epilogue_store<MODE, ML::NI, ML::MI>(acc, ep, m0 + (wid / WN) * ML::TM, n0 + (wid % WN) * ML::TN, lane, M, N);
+}
+
+// =====================================================================================================
+// Ring-pipelined main loop: BK = 32 "half-tiles" (64-B LDS rows) in a ring of SLOTS buffers, global->LDS
+// loads kept SLOTS-1 half-tiles ahead behind a COUNTED s_waitcnt vmcnt + raw s_barrier (never vmcnt(0) in
+// the loop), so HBM/L2 latency is covered by 2-3 half-steps of MFMAs instead of one.  256x128 tile with
+// 4 waves keeps LDS at 72 KB -> two blocks per CU, whose epilogues overlap each other's main loops.
+// LDS image: [rows][32 elem]; 16-B chunk p of row r holds logical chunk p ^ G[(r>>2)&3], G = {0,3,2,1}
+// (conflict-free for the 16x16x32 fragment ds_read_b128; applied on the per-lane SOURCE address).
+template <int ROWS, int NT>
+__device__ __forceinline__ void ring_stage(const uint16_t* __restrict__ G, int64_t ld, int row0, int row_max, int k0,
+                                           char* tile, int tid) {
+    constexpr int IT = ROWS * 4 / NT;
+    static_assert(ROWS * 4 % NT == 0, "half-tile rows must fill whole passes");
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int cid = it * NT + tid;
+        const int row = cid >> 2, pc = cid & 3;
+        const int c = pc ^ ((4 - ((row >> 2) & 3)) & 3);
+        int grow = row0 + row;
+        grow = grow < row_max ? grow : row_max;
+        const uint16_t* src = G + (int64_t)grow * ld + k0 + c * 8;
+        char* dst = tile + (it * NT + (tid & ~63)) * 16;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)dst, 16, 0, 0);
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else static_assert(N < 0, "add the vmcnt literal");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int SLOTS>
+struct GemmRing {
+    static constexpr int NT = WM * WN * 64;
+    static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    static constexpr int A_BYTES = BM * 64, W_BYTES = BN * 64, SLOT_BYTES = A_BYTES + W_BYTES;
+    static constexpr int SMEM_BYTES = SLOTS * SLOT_BYTES;
+    static constexpr int LPH = (BM + BN) * 4 / NT;          // global_load_lds per wave per half-tile
+    static constexpr int DEPTH = SLOTS - 1;                 // half-tiles in flight ahead of the one being computed
+    using vec = typename Mfma<T>::vec;
+
+    static __device__ __forceinline__ void issue(const uint16_t* Ag, int64_t lda, int M, const uint16_t* Wg, int64_t ldw,
+                                                 int N, int m0, int n0, int h, char* smem, int tid) {
+        char* slot = smem + (h % SLOTS) * SLOT_BYTES;
+        ring_stage<BM, NT>(Ag, lda, m0, M - 1, h * 32, slot, tid);
+        ring_stage<BN, NT>(Wg, ldw, n0, N - 1, h * 32, slot + A_BYTES, tid);
+    }
+
+    static __device__ __forceinline__ void run(const T* __restrict__ A, int64_t lda, int M, const T* __restrict__ W,
+                                               int64_t ldw, int N, int K, int m0, int n0, char* smem,
+                                               f32x4 (&acc)[NI][MI]) {
+        const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+        const int wm = wid / WN, wn = wid % WN;
+        const uint16_t* Ag = reinterpret_cast<const uint16_t*>(A);
+        const uint16_t* Wg = reinterpret_cast<const uint16_t*>(W);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int frow = lane & 15, fq = lane >> 4;
+        const int off = frow * 64 + ((fq ^ ((4 - ((lane >> 2) & 3)) & 3)) << 4);
+        const int a_base = wm * TM * 64 + off, w_base = A_BYTES + wn * TN * 64 + off;
+        const int nh = K >> 5;
+        static_assert(DEPTH == 2 || DEPTH == 3, "ring depth");
+#pragma unroll
+        for (int h = 0; h < DEPTH; ++h)
+            if (h < nh) issue(Ag, lda, M, Wg, ldw, N, m0, n0, h, smem, tid);
+        for (int h = 0; h < nh; ++h) {
+            // half-tile h must have landed: all but the (DEPTH-1) younger half-tiles' loads retired
+            const int younger = (nh - 1 - h) < (DEPTH - 1) ? (nh - 1 - h) : (DEPTH - 1);
+            if (younger == DEPTH - 1) wait_vmcnt<LPH * (DEPTH - 1)>();
+            else if (DEPTH == 3 && younger == 1) wait_vmcnt<LPH>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();          // everyone's part of h landed; everyone done reading slot (h-1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (h + DEPTH < nh) issue(Ag, lda, M, Wg, ldw, N, m0, n0, h + DEPTH, smem, tid);
+            const char* slot = smem + (h % SLOTS) * SLOT_BYTES;
+            vec af[MI], wf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec*>(slot + a_base + i * 1024);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const vec*>(slot + w_base + j * 1024);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<T>::mma(wf[j], af[i], acc[j][i]);
+        }
+    }
+};
+
+// ---- epilogue v2: lane exchange -> each lane owns 8 consecutive n (16-B stores, 64-B row segments) ------
+// fast erf-GELU: Abramowitz-Stegun 7.1.26 (|erf error| < 1.5e-7), one v_rcp + one v_exp per element
+__device__ __forceinline__ float gelu_fast(float v) {
+    const float x = fabsf(v) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
+    const float erf_abs = 1.0f - p * e;                       // erf(|v|/sqrt2)
+    return 0.5f * v + 0.5f * fabsf(v) * erf_abs;              // 0.5 v (1 + sign(v) erf(|v|/sqrt2))
+}
+
+template <int MODE, int NI, int MI>
+__device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], const EpiParams& p, int m_base, int n_base,
+                                                  int lane, int M, int N) {
+    static_assert(NI % 2 == 0, "pairs of 16-column blocks");
+    const int mq = lane & 15, q = lane >> 4, odd = q & 1;
+#pragma unroll
+    for (int jp = 0; jp < NI / 2; ++jp) {
+        const int n = n_base + (2 * jp + odd) * 16 + (q >> 1) * 8;
+        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (n < N) { b0 = *reinterpret_cast<const f32x4*>(p.bias + n); b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const f32x4 keep = odd ? acc[2 * jp + 1][i] : acc[2 * jp][i];
+            const f32x4 send = odd ? acc[2 * jp][i] : acc[2 * jp + 1][i];
+            f32x4 recv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) recv[r] = __shfl_xor(send[r], 16);
+            const f32x4 lo = odd ? recv : keep, hi = odd ? keep : recv;
+            const int m = m_base + i * 16 + mq;
+            if (m >= M || n >= N) continue;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = lo[r] + b0[r]; v[4 + r] = hi[r] + b1[r]; }
+            if constexpr (MODE == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
+            }
+            if constexpr (MODE == EPI_BIAS_RESID) {
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(p.resid + (int64_t)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { float a, b; unpack_bf16x2(rr[r], a, b); v[2 * r] += a; v[2 * r + 1] += b; }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = pack_bf16x2(v[2 * r], v[2 * r + 1]);
+            *reinterpret_cast<u32x4*>(p.out + (int64_t)m * p.ldc + n) = o;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int SLOTS, int MODE>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_ring_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                   const bf16_t* __restrict__ W, int64_t ldw,
+                                                                   int M, int N, int K, int tiles_m, int tiles_n,
+                                                                   EpiParams ep) {
+    using ML = GemmRing<bf16_t, BM, BN, WM, WN, SLOTS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tile_m = t / tiles_n, tile_n = t % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f32x4 acc[ML::NI][ML::MI];
+    ML::run(A, lda, M, W, ldw, N, K, m0, n0, smem, acc);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    epilogue_store_v2<MODE, ML::NI, ML::MI>(acc, ep, m0 + (wid / WN) * ML::TM, n0 + (wid % WN) * ML::TN, lane, M, N);
+}
+
+// v0 main loop with the v2 epilogue (isolates the epilogue change)
+template <int BM, int BN, int WM, int WN, int MODE, int OPT = 0>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_v0e2_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                   const bf16_t* __restrict__ W, int64_t ldw,
+                                                                   int M, int N, int K, int tiles_m, int tiles_n,
+                                                                   EpiParams ep) {
+    using ML = GemmMainloop<bf16_t, BM, BN, WM, WN, true, OPT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tile_m = t / tiles_n, tile_n = t % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f32x4 acc[ML::NI][ML::MI];
+    const int koff = (OPT & 64) ? tile_n * 2 : ((OPT & 128) ? tile_n : ((OPT & 256) ? tile_n * 4 : 0));
+    ML::run(A, lda, M, W, ldw, N, K, m0, n0, smem, acc, koff);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    epilogue_store_v2<MODE, ML::NI, ML::MI>(acc, ep, m0 + (wid / WN) * ML::TM, n0 + (wid % WN) * ML::TN, lane, M, N);
 }

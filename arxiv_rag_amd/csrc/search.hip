@@ -19,6 +19,7 @@
 #define KMAX 32                      // largest k
 #define KSEL_SMALL 16                 // groups rescored when k <= 10
 #define KSEL_BIG 40                   // groups rescored when k <= 32
+#define SUPER 16                      // groups per super-group in the selection pass
 #define SEL_SPLIT_WAVES 4            // waves per select block
 #define QBATCH_MAX 1024              // queries per internal pass (bounds the gmax workspace)
 
@@ -72,12 +73,16 @@ __device__ __forceinline__ void topk_insert(float (&s)[K], int64_t (&id)[K], flo
     }
 }
 
-// pass B1, stage 1: lane = query, each wave scans a slice of groups and keeps its top-K groups.
-// grid (Qpad/64, nsplit), block 256.  out: part_s/part_g [nsplit*4][Qpad][K]
+// pass B1, stage 1: lane = query, each wave scans a slice of groups (coalesced over queries) keeping its
+// top-K groups in registers; the block's 4 waves then merge through LDS -> ONE list per (block slice, query).
+// grid (Qpad/64, nsplit), block 256.  out: part_s/part_g [nsplit][Qpad][K]
 template <int K>
 __global__ __launch_bounds__(256) void select_groups_kernel(const float* __restrict__ gmax, int64_t ldg, int64_t n_groups,
-                                                             int nq, int nsplit, float* __restrict__ part_s,
-                                                             int32_t* __restrict__ part_g) {
+                                                             int64_t n_real, int nq, int nsplit,
+                                                             float* __restrict__ part_s, int32_t* __restrict__ part_g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ls = reinterpret_cast<float*>(smem);                     // [4][K][64]
+    int32_t* lg = reinterpret_cast<int32_t*>(smem + 4 * K * 64 * 4);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int q = blockIdx.x * 64 + lane;
     const int slice = blockIdx.y * SEL_SPLIT_WAVES + w, nslices = nsplit * SEL_SPLIT_WAVES;
@@ -86,22 +91,52 @@ __global__ __launch_bounds__(256) void select_groups_kernel(const float* __restr
     float s[K]; int64_t id[K];
 #pragma unroll
     for (int p = 0; p < K; ++p) { s[p] = -INFINITY; id[p] = 0x7fffffff; }
-    if (q < nq) {
-        for (int64_t g = g0; g < g1; ++g) {
-            const float v = gmax[g * ldg + q];
-            if (v > s[K - 1]) topk_insert<K>(s, id, v, g);      // increasing g: ties keep the lower group
+    const int qc = q < nq ? q : nq - 1;                                // clamp: every lane loads (results unused)
+    const float* col = gmax + qc;
+    // g0..g1 count SUPER-groups of SUPER consecutive groups: one max per super-group (no divergence), then
+    // one threshold test per super-group.  The true top-K groups lie inside the top-K super-groups (same
+    // "beaten K times" argument one level up); the rescore kernel expands them again.
+    for (int64_t sg = g0; sg < g1; ++sg) {
+        float v[SUPER];
+#pragma unroll
+        for (int u = 0; u < SUPER; ++u) {
+            const int64_t g = sg * SUPER + u;
+            v[u] = col[(g < n_real ? g : n_real - 1) * ldg];
+        }
+        float m = v[0];
+#pragma unroll
+        for (int u = 1; u < SUPER; ++u) m = fmaxf(m, v[u]);
+        if (m > s[K - 1]) topk_insert<K>(s, id, m, sg);                // increasing sg: ties keep the lower one
+    }
+#pragma unroll
+    for (int p = 0; p < K; ++p) { ls[(w * K + p) * 64 + lane] = s[p]; lg[(w * K + p) * 64 + lane] = (int32_t)id[p]; }
+    __syncthreads();
+    if (w == 0) {
+        int ptr[SEL_SPLIT_WAVES] = {0, 0, 0, 0};
+        const int64_t o = ((int64_t)blockIdx.y * ldg + q) * K;
+        for (int p = 0; p < K; ++p) {
+            float bs = -INFINITY; int bg = 0x7fffffff; int bw = 0;
+#pragma unroll
+            for (int ww = 0; ww < SEL_SPLIT_WAVES; ++ww) {
+                const int pp = ptr[ww] < K ? ptr[ww] : K - 1;
+                const float cs = ptr[ww] < K ? ls[(ww * K + pp) * 64 + lane] : -INFINITY;
+                const int cg = ptr[ww] < K ? lg[(ww * K + pp) * 64 + lane] : 0x7fffffff;
+                if (cs > bs || (cs == bs && cg < bg)) { bs = cs; bg = cg; bw = ww; }
+            }
+#pragma unroll
+            for (int ww = 0; ww < SEL_SPLIT_WAVES; ++ww) ptr[ww] += (ww == bw) ? 1 : 0;
+            part_s[o + p] = bs;
+            part_g[o + p] = (bg == 0x7fffffff) ? -1 : bg;
         }
     }
-    const int64_t o = ((int64_t)slice * ldg + q) * K;
-#pragma unroll
-    for (int p = 0; p < K; ++p) { part_s[o + p] = s[p]; part_g[o + p] = (int32_t)(id[p] == 0x7fffffff ? -1 : id[p]); }
 }
 
 // block-wide argmax over (score desc, id asc); ids < 0 are empty slots. Returns winner index in LDS arrays.
-__device__ __forceinline__ int block_argbest(const float* s, const int64_t* id, int n, int tid, int nt, float* red_s,
+template <int NT>
+__device__ __forceinline__ int block_argbest(const float* s, const int64_t* id, int n, int tid, float* red_s,
                                              int64_t* red_i, int* red_p) {
     float bs = -INFINITY; int64_t bi = INT64_MAX; int bp = -1;
-    for (int i = tid; i < n; i += nt) {
+    for (int i = tid; i < n; i += NT) {
         const float v = s[i]; const int64_t vi = id[i];
         if (vi < 0) continue;
         if (bp < 0 || v > bs || (v == bs && vi < bi)) { bs = v; bi = vi; bp = i; }
@@ -115,7 +150,8 @@ __device__ __forceinline__ int block_argbest(const float* s, const int64_t* id, 
     if ((tid & 63) == 0) { red_s[w] = bs; red_i[w] = bi; red_p[w] = bp; }
     __syncthreads();
     bs = red_s[0]; bi = red_i[0]; bp = red_p[0];
-    for (int k = 1; k < (nt >> 6); ++k) {
+#pragma unroll
+    for (int k = 1; k < NT / 64; ++k) {
         const float os = red_s[k]; const int64_t oi = red_i[k]; const int op = red_p[k];
         if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
     }
@@ -123,63 +159,78 @@ __device__ __forceinline__ int block_argbest(const float* s, const int64_t* id, 
     return bp;
 }
 
-// pass B1 stage 2 + pass B2: one block (256 thr) per query.
+// pass B1 stage 2 + pass B2: one block of 16 waves per query.  Wave w rescoring group w (, w+16, ...):
+// 16 lanes per corpus row, 4 rows per step, query row staged in LDS.
+#define RS_NT 1024
 template <int K>
-__global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ part_s, const int32_t* __restrict__ part_g,
-                                                       int nslices, int64_t ldg, const f16_t* __restrict__ Q,
-                                                       const f16_t* __restrict__ C, int64_t n_rows, int D, int k,
-                                                       float* __restrict__ out_s, int64_t* __restrict__ out_i,
-                                                       int64_t idx_base) {
+__global__ __launch_bounds__(RS_NT) void rescore_kernel(const float* __restrict__ part_s, const int32_t* __restrict__ part_g,
+                                                         int nslices, int64_t ldg, const float* __restrict__ gmax,
+                                                         int64_t n_groups, const f16_t* __restrict__ Q,
+                                                         const f16_t* __restrict__ C, int64_t n_rows, int D, int k,
+                                                         float* __restrict__ out_s, int64_t* __restrict__ out_i,
+                                                         int64_t idx_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float red_s[4]; __shared__ int64_t red_i[4]; __shared__ int red_p[4];
+    __shared__ float red_s[RS_NT / 64]; __shared__ int64_t red_i[RS_NT / 64]; __shared__ int red_p[RS_NT / 64];
     __shared__ int32_t sel_g[K];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int ncand = nslices * K;
-    float* cs = reinterpret_cast<float*>(smem);                       // [ncand] then reused: [K*64] scores
-    int64_t* ci = reinterpret_cast<int64_t*>(smem + (((size_t)(ncand > K * GROUP_ROWS ? ncand : K * GROUP_ROWS) * 4 + 15) & ~(size_t)15));
-    for (int i = tid; i < ncand; i += 256) {
+    const int nmax = ncand > K * GROUP_ROWS ? ncand : K * GROUP_ROWS;
+    static_assert(SUPER <= GROUP_ROWS, "expanded candidates must fit the score buffer");
+    float* cs = reinterpret_cast<float*>(smem);                                     // [nmax]
+    int64_t* ci = reinterpret_cast<int64_t*>(smem + (((size_t)nmax * 4 + 15) & ~(size_t)15));   // [nmax]
+    f16_t* qs = reinterpret_cast<f16_t*>(reinterpret_cast<char*>(ci) + (size_t)nmax * 8);        // [D]
+    for (int i = tid; i < ncand; i += RS_NT) {
         const int sl = i / K, p = i % K;
         const int64_t o = ((int64_t)sl * ldg + q) * K + p;
         cs[i] = part_s[o]; ci[i] = part_g[o];
     }
+    for (int i = tid; i < (D >> 3); i += RS_NT)
+        reinterpret_cast<u32x4*>(qs)[i] = reinterpret_cast<const u32x4*>(Q + (int64_t)q * D)[i];
     __syncthreads();
-    for (int r = 0; r < K; ++r) {
-        const int bp = block_argbest(cs, ci, ncand, tid, 256, red_s, red_i, red_p);
+    for (int r = 0; r < K; ++r) {                                    // top-K super-groups
+        const int bp = block_argbest<RS_NT>(cs, ci, ncand, tid, red_s, red_i, red_p);
+        if (tid == 0) { sel_g[r] = bp >= 0 ? (int32_t)ci[bp] : -1; if (bp >= 0) ci[bp] = -1; }
+        __syncthreads();
+    }
+    for (int i = tid; i < K * SUPER; i += RS_NT) {                   // expand to their K*SUPER groups
+        const int sg = sel_g[i / SUPER];
+        const int64_t g = (int64_t)sg * SUPER + (i % SUPER);
+        const bool ok = sg >= 0 && g < n_groups;
+        cs[i] = ok ? gmax[g * ldg + q] : -INFINITY;
+        ci[i] = ok ? g : -1;
+    }
+    __syncthreads();
+    for (int r = 0; r < K; ++r) {                                    // top-K groups
+        const int bp = block_argbest<RS_NT>(cs, ci, K * SUPER, tid, red_s, red_i, red_p);
         if (tid == 0) { sel_g[r] = bp >= 0 ? (int32_t)ci[bp] : -1; if (bp >= 0) ci[bp] = -1; }
         __syncthreads();
     }
     // exact scores of the K selected groups
-    const int nch = D >> 3;
-    const f16_t* qrow = Q + (int64_t)q * D;
-    f16x8 qv[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int ch = lane + 64 * c;
-        if (ch < nch) qv[c] = *reinterpret_cast<const f16x8*>(qrow + ch * 8);
-        else qv[c] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    for (int rr = w; rr < K * GROUP_ROWS; rr += 4) {
-        const int gsel = sel_g[rr / GROUP_ROWS];
-        const int64_t row = (int64_t)gsel * GROUP_ROWS + (rr % GROUP_ROWS);
-        float sc = -INFINITY; int64_t rid = -1;
-        if (gsel >= 0 && row < n_rows) {
-            const f16_t* crow = C + row * D;
+    const int nch = D >> 3, l16 = lane & 15, rsub = lane >> 4;
+    for (int gi = w; gi < K; gi += RS_NT / 64) {
+        const int gsel = sel_g[gi];
+#pragma unroll 2
+        for (int r4 = 0; r4 < GROUP_ROWS; r4 += 4) {
+            const int rr = r4 + rsub;
+            const int64_t row = (int64_t)gsel * GROUP_ROWS + rr;
+            const bool ok = gsel >= 0 && row < n_rows;
             float a = 0.f;
-            // D <= 128*8: chunks beyond the second are looped
-            for (int ch = lane; ch < nch; ch += 64) {
-                const f16x8 cv = *reinterpret_cast<const f16x8*>(crow + ch * 8);
-                const f16x8 qq = (ch < 64) ? qv[0] : ((ch < 128) ? qv[1] : *reinterpret_cast<const f16x8*>(qrow + ch * 8));
+            if (ok) {
+                const f16_t* crow = C + row * D;
+                for (int ch = l16; ch < nch; ch += 16) {
+                    const f16x8 cv = *reinterpret_cast<const f16x8*>(crow + ch * 8);
+                    const f16x8 qq = *reinterpret_cast<const f16x8*>(qs + ch * 8);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a = fmaf((float)cv[e], (float)qq[e], a);
+                    for (int e = 0; e < 8; ++e) a = fmaf((float)cv[e], (float)qq[e], a);
+                }
             }
-            a = wave_sum(a);
-            sc = a; rid = row;
+            a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+            if (l16 == 0) { cs[gi * GROUP_ROWS + rr] = ok ? a : -INFINITY; ci[gi * GROUP_ROWS + rr] = ok ? row : -1; }
         }
-        if (lane == 0) { cs[rr] = sc; ci[rr] = rid; }
     }
     __syncthreads();
     for (int r = 0; r < k; ++r) {
-        const int bp = block_argbest(cs, ci, K * GROUP_ROWS, tid, 256, red_s, red_i, red_p);
+        const int bp = block_argbest<RS_NT>(cs, ci, K * GROUP_ROWS, tid, red_s, red_i, red_p);
         if (tid == 0) {
             out_s[(int64_t)q * k + r] = bp >= 0 ? cs[bp] : -INFINITY;
             out_i[(int64_t)q * k + r] = bp >= 0 ? ci[bp] + idx_base : -1;
@@ -259,13 +310,14 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k) {
     const int qb = nq < QBATCH_MAX ? nq : QBATCH_MAX;
     w.ldg = round_up64(qb, 64);
     w.n_groups = (n_rows + GROUP_ROWS - 1) / GROUP_ROWS;
-    int64_t ns = (w.n_groups + 4 * 512 - 1) / (4 * 512);       // ~512 groups per wave-slice
-    w.nsplit = (int)(ns < 1 ? 1 : (ns > 32 ? 32 : ns));
+    const int64_t n_super = (w.n_groups + SUPER - 1) / SUPER;
+    int64_t ns = (n_super + 4 * 8 - 1) / (4 * 8);               // ~8 super-groups per wave-slice
+    w.nsplit = (int)(ns < 1 ? 1 : (ns > 256 ? 256 : ns));
     int64_t o = 0;
     auto take = [&](int64_t b) { int64_t r = o; o += round_up64(b, 256); return r; };
     w.gmax = take(w.n_groups * w.ldg * 4);
-    w.part_s = take((int64_t)w.nsplit * SEL_SPLIT_WAVES * w.ldg * KSEL_BIG * 4);
-    w.part_g = take((int64_t)w.nsplit * SEL_SPLIT_WAVES * w.ldg * KSEL_BIG * 4);
+    w.part_s = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
+    w.part_g = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
     w.total = o;
     return w;
 }
@@ -298,16 +350,23 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
     float* gmax = (float*)(ws + L.gmax);
     float* ps = (float*)(ws + L.part_s);
     int32_t* pg = (int32_t*)(ws + L.part_g);
-    dim3 grid(cdiv(nq, 64), L.nsplit);
     {
+        dim3 grid(cdiv(nq, 64), L.nsplit);
+        const int smem_sel = SEL_SPLIT_WAVES * K * 64 * 8;
+        auto ksel = select_groups_kernel<K>;
+        static bool sel_attr = false;
+        if (!sel_attr && smem_sel > 48 * 1024) {
+            ARX_HIP_CHECK(hipFuncSetAttribute((const void*)ksel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sel));
+            sel_attr = true;
+        }
         ProfScope psc(ARX_K_SEARCH_SELECT, st);
-        select_groups_kernel<K><<<grid, 256, 0, st>>>(gmax, L.ldg, L.n_groups, nq, L.nsplit, ps, pg);
+        ksel<<<grid, 256, smem_sel, st>>>(gmax, L.ldg, (L.n_groups + SUPER - 1) / SUPER, L.n_groups, nq, L.nsplit, ps, pg);
         ARX_HIP_CHECK(hipGetLastError());
     }
-    const int nslices = L.nsplit * SEL_SPLIT_WAVES;
+    const int nslices = L.nsplit;
     const int ncand = nslices * K;
     const int nmax = ncand > K * GROUP_ROWS ? ncand : K * GROUP_ROWS;
-    const size_t smem = (((size_t)nmax * 4 + 15) & ~(size_t)15) + (size_t)nmax * 8;
+    const size_t smem = (((size_t)nmax * 4 + 15) & ~(size_t)15) + (size_t)nmax * 8 + (size_t)D * 2;
     auto kern = rescore_kernel<K>;
     static size_t attr_max = 0;
     if (smem > 48 * 1024 && smem > attr_max) {
@@ -315,7 +374,7 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
         attr_max = smem;
     }
     ProfScope psc(ARX_K_SEARCH_RESCORE, st);
-    kern<<<nq, 256, smem, st>>>(ps, pg, nslices, L.ldg, Q, C, n_rows, D, k, out_s, out_i, idx_base);
+    kern<<<nq, RS_NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }

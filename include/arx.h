@@ -135,6 +135,12 @@ int32_t arx_topk_search(const void* corpus, int64_t n_rows, const void* queries,
 int32_t arx_topk_merge(const float* scores, const int64_t* ids, int32_t n_parts, int32_t n_queries,
                        int32_t k, float* out_scores, int64_t* out_ids, void* stream);
 
+/* Raw linear layer of the path: C[M,N] (bf16) = epi(A[M,K] (bf16) x W[N,K]^T (bf16) + bias[N] (f32)),
+ * mode 0 = bias, 1 = bias + erf-GELU, 2 = bias + resid[M,N] (bf16).  K % 64 == 0, N % 8 == 0.
+ * `variant` selects the main-loop schedule (see csrc/encoder.hip); exposed for unit tests and tuning. */
+int32_t arx_gemm_bf16(const void* A, const void* W, const float* bias, const void* resid, void* C,
+                      int32_t M, int32_t N, int32_t K, int32_t mode, int32_t variant, void* stream);
+
 /* ---- small device helpers the host code needs (all on `stream`) -------------------------------- */
 /* f32 [n] -> bf16 [n] round-to-nearest-even (weight upload). */
 int32_t arx_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""GEMM variant A/B on the GPU box: correctness vs torch fp32 matmul on a row subset + timing (torch events,
+interleaved rounds in one process).  usage: gemm_bench.py [variants...]"""
+import sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+import torch
+from arxiv_rag_amd import _lib
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2, 3]
+M = 262144
+shapes = [("qkv", 2304, 768, 0), ("oproj", 768, 768, 2), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 2)]
+st = torch.cuda.current_stream().cuda_stream
+g = torch.Generator(device=dev); g.manual_seed(0)
+
+def run(v, A, W, b, R, C, mode):
+    Mm, K = A.shape; N = W.shape[0]
+    rc = lib.arx_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr() if R is not None else None, C.data_ptr(),
+                           Mm, N, K, mode, v, st)
+    _lib.check(rc, "arx_gemm_bf16")
+
+def ref(A, W, b, R, mode, rows):
+    y = A[rows].float() @ W.float().T + b
+    if mode == 1: y = torch.nn.functional.gelu(y)
+    if mode == 2: y = y + R[rows].float()
+    return y
+
+print("device", torch.cuda.get_device_name(0))
+import os
+FAST = os.environ.get("GEMM_BENCH_FAST") == "1"
+# small odd shapes first (masking paths)
+for (Mm, N, K) in () if FAST else ((230, 192, 64), (517, 64, 128), (1000, 384, 384), (300, 1536, 384), (777, 768, 768)):
+    A = (torch.randn((Mm, K), device=dev, generator=g)).to(torch.bfloat16)
+    W = (torch.randn((N, K), device=dev, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn((N,), device=dev, generator=g)
+    R = torch.randn((Mm, N), device=dev, generator=g).to(torch.bfloat16)
+    for mode in (0, 1, 2):
+        want = ref(A, W, b, R, mode, torch.arange(Mm, device=dev))
+        for v in variants:
+            C = torch.full((Mm, N), float("nan"), device=dev, dtype=torch.bfloat16)
+            run(v, A, W, b, R, C, mode)
+            err = (C.float() - want).abs().max().item()
+            ok = err < 0.03 * max(1.0, want.abs().max().item())
+            if not ok: print(f"  SMALL M{Mm} N{N} K{K} mode{mode} v{v}: maxerr {err:.4f} {'ok' if ok else 'FAIL'}")
+print("small shapes checked")
+for name, N, K, mode in shapes:
+    A = (torch.randn((M, K), device=dev, generator=g)).to(torch.bfloat16)
+    W = (torch.randn((N, K), device=dev, generator=g) * 0.03).to(torch.bfloat16)
+    b = torch.randn((N,), device=dev, generator=g) * 0.1
+    R = torch.randn((M, N), device=dev, generator=g).to(torch.bfloat16) if mode == 2 else None
+    C = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
+    rows = torch.cat([torch.arange(0, 300, device=dev), torch.arange(M - 300, M, device=dev), torch.randint(0, M, (400,), device=dev, generator=g)])
+    want = ref(A, W, b, R, mode, rows)
+    flops = 2.0 * M * N * K
+    res = {}
+    for v in variants:
+        C.fill_(float("nan"))
+        run(v, A, W, b, R, C, mode)
+        err = (C[rows].float() - want).abs().max().item()
+        nan = torch.isnan(C.float()).any().item()
+        res[v] = {"err": err, "nan": nan, "t": []}
+    for rnd in range(1 if FAST else 5):
+        for v in variants:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(2 if FAST else 5): run(v, A, W, b, R, C, mode)
+            e1.record(); e1.synchronize()
+            res[v]["t"].append(e0.elapsed_time(e1) / (2 if FAST else 5))
+    for v in variants:
+        t = np.median(res[v]["t"]); tm = min(res[v]["t"])
+        print(f"{name:6s} N={N:5d} K={K:5d} mode{mode} v{v}: {t:7.3f} ms (min {tm:.3f})  {flops/t/1e9:7.1f} TF   maxerr {res[v]['err']:.4f} nan={res[v]['nan']}")
