@@ -37,12 +37,19 @@ struct arx_encoder {
     float* bias_tbl = nullptr;
     uint16_t* tap = nullptr;
     int tap_layer = -1;
+    // LayerNorm folding (ln_fold = 1): derived weights + per-row statistics, all private to the handle
+    int ln_fold = 1;
+    char* fold_ws = nullptr;
+    std::vector<uint16_t*> wqkv_f, wfc1_f;      // per layer: gamma-folded copies (wqkv_f[0] unused)
+    std::vector<float*> s_qkv, c_qkv, s_fc1, c_fc1;
+    float *st1_sum = nullptr, *st1_sq = nullptr, *st2_sum = nullptr, *st2_sq = nullptr;   // row mean / rstd of y1 / y2
+    float *part_s = nullptr, *part_q = nullptr;                                              // [H/64][tok_pad] partial slabs
     int variant = 13;
     int attn_variant = 1;
 };
 
 struct WsLayout {
-    int64_t cu, x, x1, qkv, ctx, y, hbuf, bias, total;
+    int64_t cu, x, x1, qkv, ctx, y, hbuf, bias, stats, total;
 };
 static WsLayout ws_layout(const arx_encoder_config& c, int max_tokens, int max_seqs) {
     const int64_t tp = round_up64(max_tokens, 256);
@@ -57,6 +64,7 @@ static WsLayout ws_layout(const arx_encoder_config& c, int max_tokens, int max_s
     l.y = take(tp * c.hidden * 2);
     l.hbuf = take(tp * c.ffn * 2);
     l.bias = take((int64_t)c.heads * ARX_BIAS_ROW * 4);
+    l.stats = take(tp * 4 * 4 + 2 * (int64_t)(c.hidden / 64) * tp * 4);   // mean/rstd x2 + partial slabs
     l.total = o;
     return l;
 }
@@ -125,6 +133,48 @@ extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_e
     h->y = (uint16_t*)(h->ws + l.y);
     h->hbuf = (uint16_t*)(h->ws + l.hbuf);
     h->bias_tbl = (float*)(h->ws + l.bias);
+    {
+        const int64_t tp = round_up64(max_tokens, 256);
+        float* st = (float*)(h->ws + l.stats);
+        h->st1_sum = st; h->st1_sq = st + tp; h->st2_sum = st + 2 * tp; h->st2_sq = st + 3 * tp;
+        h->part_s = st + 4 * tp; h->part_q = h->part_s + (int64_t)(cfg->hidden / 64) * tp;
+    }
+    const char* lf = getenv("ARX_LN_FOLD");
+    h->ln_fold = lf ? atoi(lf) : 1;
+    if (h->ln_fold) {
+        // derived weights: per layer  W_fc1 o gamma1 (+ s, c), and for layers >= 1  W_qkv o gamma2 of the previous layer
+        const int64_t H = cfg->hidden, F = cfg->ffn, Lc = cfg->layers;
+        const int64_t per = round_up64(3 * H * H * 2, 256) + round_up64(F * H * 2, 256) + 2 * round_up64(3 * H * 4, 256) + 2 * round_up64(F * 4, 256);
+        he = hipMalloc((void**)&h->fold_ws, per * Lc);
+        if (he != hipSuccess) {
+            arx_set_error("hipMalloc(folded weights): %s", hipGetErrorString(he));
+            (void)hipFree(h->ws);
+            delete h;
+            return ARX_ERR_HIP;
+        }
+        char* pws = h->fold_ws;
+        auto takep = [&](int64_t bytes) { char* r = pws; pws += round_up64(bytes, 256); return r; };
+        for (int i = 0; i < Lc; ++i) {
+            const arx_layer_weights& L = h->layers[i];
+            uint16_t* wq = (uint16_t*)takep(3 * H * H * 2); uint16_t* w1 = (uint16_t*)takep(F * H * 2);
+            float* sq = (float*)takep(3 * H * 4); float* cq = (float*)takep(3 * H * 4);
+            float* s1 = (float*)takep(F * 4); float* c1 = (float*)takep(F * 4);
+            h->wqkv_f.push_back(wq); h->wfc1_f.push_back(w1);
+            h->s_qkv.push_back(sq); h->c_qkv.push_back(cq); h->s_fc1.push_back(s1); h->c_fc1.push_back(c1);
+            fold_ln_kernel<<<cdiv(F, 4), 256>>>((const uint16_t*)L.w_fc1, L.ln1_g, L.ln1_b, L.b_fc1, w1, s1, c1, (int)F, (int)H);
+            if (i > 0) {
+                const arx_layer_weights& P = h->layers[i - 1];
+                fold_ln_kernel<<<cdiv(3 * H, 4), 256>>>((const uint16_t*)L.w_qkv, P.ln2_g, P.ln2_b, L.b_qkv, wq, sq, cq, (int)(3 * H), (int)H);
+            }
+        }
+        he = hipDeviceSynchronize();
+        if (he != hipSuccess) {
+            arx_set_error("fold_ln_kernel: %s", hipGetErrorString(he));
+            (void)hipFree(h->ws); (void)hipFree(h->fold_ws);
+            delete h;
+            return ARX_ERR_HIP;
+        }
+    }
     if (cfg->arch == ARX_ARCH_MPNET) {
         // Toeplitz bias rows, pre-multiplied by log2(e): tbl[h][d + C] = rel_bias[bucket(d)][h] * log2e
         std::vector<float> rb((size_t)cfg->rel_buckets * cfg->heads);
@@ -158,6 +208,7 @@ extern "C" void arx_encoder_destroy(arx_encoder* h) {
     if (!h) return;
     if (h->ws) (void)hipFree(h->ws);
     if (h->tap) (void)hipFree(h->tap);
+    if (h->fold_ws) (void)hipFree(h->fold_ws);
     delete h;
 }
 
@@ -203,48 +254,39 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
         return ARX_ERR_ARG;
     }
     const bool wide = (N % 256 == 0);
-    static bool a0 = false, a1 = false, a2 = false, a3 = false, a4 = false, a5 = false, a6 = false, a7 = false;
-    switch (variant) {
-    case 0:
-        if (wide) return launch_gemm_kernel(gemm_bf16_kernel<256, 256, 2, 4, true, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, true>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a0);
-        return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, true, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, true>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a1);
-    case 4:   // register-staged reference loop (no global_load_lds)
-        if (wide) return launch_gemm_kernel(gemm_bf16_kernel<256, 256, 2, 4, false, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, false>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a6);
-        return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, false, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, false>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a7);
-    case 1:
-        if (wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, true>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a2);
-        { static bool a3b = false;
-        return launch_gemm_kernel(gemm_v0e2_kernel<256, 128, 4, 2, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, true>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a3b); }
-#define ARX_EXP_CASE(ID, OPT)                                                                                          \
-    case ID: {                                                                                                         \
-        static bool ax = false;                                                                                        \
-        return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, OPT>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, OPT>::SMEM_BYTES, \
-                                  512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &ax);                                \
+    static bool a0 = false, a1 = false, a2 = false, a3 = false, a4 = false, a5 = false, a6 = false, a7 = false, a8 = false, a9 = false;
+    if constexpr (MODE <= EPI_BIAS_RESID) {
+        // first-version kernels (8-B stores, erff GELU): kept as the in-tree A/B reference for the epilogue work
+        if (variant == 0) {
+            if (wide) return launch_gemm_kernel(gemm_bf16_kernel<256, 256, 2, 4, true, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, true>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a0);
+            return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, true, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, true>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a1);
+        }
+        if (variant == 4) {      // register-staged loop (no global_load_lds)
+            if (wide) return launch_gemm_kernel(gemm_bf16_kernel<256, 256, 2, 4, false, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, false>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a6);
+            return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, false, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, false>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a7);
+        }
     }
-    ARX_EXP_CASE(11, 1)
-    ARX_EXP_CASE(12, 2)
-    case 13:      // default: 2-stage loop, upper-half waves issue loads mid-step, setprio around MFMA clusters,
+    switch (variant) {
+    case 1:       // 2-stage loop + 16-B-store epilogue, no stagger / setprio / k rotation
+        if (wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, true>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a2);
+        return launch_gemm_kernel(gemm_v0e2_kernel<256, 128, 4, 2, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, true>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a3);
+    case 15:      // stagger + setprio, no k rotation
+        if (wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 3>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 3>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a8);
+        [[fallthrough]];
+    case 3:       // ring 256x256, 8 waves, 4 half-tile slots
+        if (variant == 3 && wide) return launch_gemm_kernel(gemm_ring_kernel<256, 256, 2, 4, 4, MODE>, GemmRing<bf16_t, 256, 256, 2, 4, 4>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a4);
+        [[fallthrough]];
+    case 2:       // ring 256x128, 4 waves, 3 half-tile slots, 2 blocks/CU
+        if (variant != 15) return launch_gemm_kernel(gemm_ring_kernel<256, 128, 2, 2, 3, MODE>, GemmRing<bf16_t, 256, 128, 2, 2, 3>::SMEM_BYTES, 256, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a5);
+        [[fallthrough]];
+    case 13:
+    default:      // DEFAULT: 2-stage loop, upper-half waves issue loads mid-step, setprio around MFMA clusters,
                   // k-loop start rotated by 2*tile_n (blocks sharing an A panel do not miss on the same lines at once)
-        if (!wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 128, 4, 2, MODE, 67>, GemmMainloop<bf16_t, 256, 128, 4, 2, true, 67>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a3);
+        if (!wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 128, 4, 2, MODE, 67>, GemmMainloop<bf16_t, 256, 128, 4, 2, true, 67>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a9);
         {
             static bool ax13 = false;
             return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 67>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 67>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &ax13);
         }
-    ARX_EXP_CASE(15, 3)
-    ARX_EXP_CASE(14, 4)
-    ARX_EXP_CASE(18, 8 + 3)
-    ARX_EXP_CASE(19, 8 + 3 + 16)
-    ARX_EXP_CASE(20, 8 + 3 + 32)
-    ARX_EXP_CASE(21, 3 + 16)
-    ARX_EXP_CASE(22, 3 + 64)
-    ARX_EXP_CASE(23, 3 + 128)
-    ARX_EXP_CASE(24, 3 + 256)
-    case 3:
-        if (wide) return launch_gemm_kernel(gemm_ring_kernel<256, 256, 2, 4, 4, MODE>, GemmRing<bf16_t, 256, 256, 2, 4, 4>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a4);
-        [[fallthrough]];
-    case 2:
-    default:
-        return launch_gemm_kernel(gemm_ring_kernel<256, 128, 2, 2, 3, MODE>, GemmRing<bf16_t, 256, 128, 2, 2, 3>::SMEM_BYTES, 256, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a5);
     }
 }
 
@@ -296,7 +338,7 @@ template <int DH, bool HB, int NW>
 static int launch_attn_tr_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
     auto kern = attention_tr_kernel<DH, HB, NW>;
     const int Lk = (max_len + 31) & ~31;
-    const int smem = AttnSmem2<DH>::total(Lk, HB);
+    const int smem = AttnSmem3<DH>::total(Lk, HB);
     static int attr_max = 0;
     if (smem > attr_max) {
         ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -365,39 +407,96 @@ extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32
                                                                  h->w.emb_ln_g, h->w.emb_ln_b, h->x, H, c.vocab_size, c.max_pos, c.pad_id, c.ln_eps);
         ARX_HIP_CHECK(hipGetLastError());
     }
-    auto tap = [&](int layer) -> int {
-        if (h->tap_layer == layer && h->tap) ARX_HIP_CHECK(hipMemcpyAsync(h->tap, h->x, (int64_t)T * H * 2, hipMemcpyDeviceToDevice, st));
-        return ARX_OK;
-    };
-    if ((rc = tap(0)) != ARX_OK) return rc;
-
     const int ln_grid = cdiv(T, 4);
+    const int64_t tp = round_up64(h->max_tokens, 256);
+    if (!h->ln_fold) {
+        // ---- reference schedule: explicit LayerNorm kernels --------------------------------------------
+        auto tap = [&](int layer) -> int {
+            if (h->tap_layer == layer && h->tap) ARX_HIP_CHECK(hipMemcpyAsync(h->tap, h->x, (int64_t)T * H * 2, hipMemcpyDeviceToDevice, st));
+            return ARX_OK;
+        };
+        if ((rc = tap(0)) != ARX_OK) return rc;
+        for (int li = 0; li < c.layers; ++li) {
+            const arx_layer_weights& L = h->layers[li];
+            EpiParams ep;
+            ep = EpiParams{h->qkv, 3 * (int64_t)H, L.b_qkv, nullptr, 0};
+            if ((rc = launch_gemm<EPI_BIAS>(ARX_K_GEMM_QKV, h->variant, h->x, H, (const uint16_t*)L.w_qkv, H, T, 3 * H, H, ep, st)) != ARX_OK) return rc;
+            if ((rc = launch_attn(h, n_seqs, max_len, st)) != ARX_OK) return rc;
+            ep = EpiParams{h->y, H, L.b_o, h->x, H};
+            if ((rc = launch_gemm<EPI_BIAS_RESID>(ARX_K_GEMM_OPROJ, h->variant, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st)) != ARX_OK) return rc;
+            { ProfScope ps(ARX_K_LAYERNORM, st);
+              layernorm_kernel<<<ln_grid, 256, 0, st>>>(h->y, h->x1, L.ln1_g, L.ln1_b, h->cu + n_seqs, H, c.ln_eps); }
+            ARX_HIP_CHECK(hipGetLastError());
+            ep = EpiParams{h->hbuf, F, L.b_fc1, nullptr, 0};
+            if ((rc = launch_gemm<EPI_BIAS_GELU>(ARX_K_GEMM_FC1, h->variant, h->x1, H, (const uint16_t*)L.w_fc1, H, T, F, H, ep, st)) != ARX_OK) return rc;
+            ep = EpiParams{h->y, H, L.b_fc2, h->x1, H};
+            if ((rc = launch_gemm<EPI_BIAS_RESID>(ARX_K_GEMM_FC2, h->variant, h->hbuf, F, (const uint16_t*)L.w_fc2, F, T, H, F, ep, st)) != ARX_OK) return rc;
+            { ProfScope ps(ARX_K_LAYERNORM, st);
+              layernorm_kernel<<<ln_grid, 256, 0, st>>>(h->y, h->x, L.ln2_g, L.ln2_b, h->cu + n_seqs, H, c.ln_eps); }
+            ARX_HIP_CHECK(hipGetLastError());
+            if ((rc = tap(li + 1)) != ARX_OK) return rc;
+        }
+        ProfScope pps(ARX_K_POOL, st);
+        pool_norm_kernel<<<n_seqs, 256, 0, st>>>(h->x, h->cu, H, c.pool, normalize, out_f32, out_stride, (f16_t*)out_f16, out16_stride,
+                                                 nullptr, nullptr, nullptr, nullptr, 0.f);
+        ARX_HIP_CHECK(hipGetLastError());
+        return ARX_OK;
+    }
+
+    // ---- default schedule: no LayerNorm kernel inside the layer loop (gemm.h "LayerNorm is never run as a kernel") ----
+    //   x  : layer 0 -> embeddings (already normalised);  afterwards the PRE-LN2 sum y2 of the previous layer
+    //   x1 : PRE-LN1 sum y1 of the current layer;  (st1, st2) : row sums / sums of squares of y1 / y2
+    const float inv_h = 1.0f / (float)H;
+    if (h->tap_layer == 0 && h->tap) ARX_HIP_CHECK(hipMemcpyAsync(h->tap, h->x, (int64_t)T * H * 2, hipMemcpyDeviceToDevice, st));
     for (int li = 0; li < c.layers; ++li) {
         const arx_layer_weights& L = h->layers[li];
         EpiParams ep;
-        // qkv = x Wqkv^T + b
-        ep = EpiParams{h->qkv, 3 * (int64_t)H, L.b_qkv, nullptr, 0};
-        if ((rc = launch_gemm<EPI_BIAS>(ARX_K_GEMM_QKV, h->variant, h->x, H, (const uint16_t*)L.w_qkv, H, T, 3 * H, H, ep, st)) != ARX_OK) return rc;
+        if (li == 0) {
+            ep = EpiParams{h->qkv, 3 * (int64_t)H, L.b_qkv, nullptr, 0};
+            if ((rc = launch_gemm<EPI_BIAS>(ARX_K_GEMM_QKV, h->variant, h->x, H, (const uint16_t*)L.w_qkv, H, T, 3 * H, H, ep, st)) != ARX_OK) return rc;
+        } else {
+            ep = EpiParams{h->qkv, 3 * (int64_t)H, h->c_qkv[li], nullptr, 0};
+            ep.a_sum = h->st2_sum; ep.a_sq = h->st2_sq; ep.s_vec = h->s_qkv[li]; ep.inv_h = inv_h; ep.eps = c.ln_eps;
+            if ((rc = launch_gemm<EPI_LN_BIAS>(ARX_K_GEMM_QKV, h->variant, h->x, H, h->wqkv_f[li], H, T, 3 * H, H, ep, st)) != ARX_OK) return rc;
+        }
         if ((rc = launch_attn(h, n_seqs, max_len, st)) != ARX_OK) return rc;
-        // y = ctx Wo^T + b + x ; x1 = LN(y)
-        ep = EpiParams{h->y, H, L.b_o, h->x, H};
-        if ((rc = launch_gemm<EPI_BIAS_RESID>(ARX_K_GEMM_OPROJ, h->variant, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st)) != ARX_OK) return rc;
+        // y1 = ctx Wo^T + b + (x0 | LN2_prev(y2))  -> x1, statistics -> st1
+        ep = EpiParams{h->x1, H, L.b_o, h->x, H};
+        ep.o_sum = h->part_s; ep.o_sq = h->part_q; ep.o_ld = tp; ep.inv_h = inv_h; ep.eps = c.ln_eps;
+        if (li == 0) {
+            if ((rc = launch_gemm<EPI_RESID_STATS>(ARX_K_GEMM_OPROJ, h->variant, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st)) != ARX_OK) return rc;
+        } else {
+            const arx_layer_weights& P = h->layers[li - 1];
+            ep.r_sum = h->st2_sum; ep.r_sq = h->st2_sq; ep.r_gamma = P.ln2_g; ep.r_beta = P.ln2_b;
+            if ((rc = launch_gemm<EPI_LNRESID_STATS>(ARX_K_GEMM_OPROJ, h->variant, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st)) != ARX_OK) return rc;
+        }
         { ProfScope ps(ARX_K_LAYERNORM, st);
-        layernorm_kernel<<<ln_grid, 256, 0, st>>>(h->y, h->x1, L.ln1_g, L.ln1_b, h->cu + n_seqs, H, c.ln_eps); }
+          ln_finalize_kernel<<<cdiv(T, 256), 256, 0, st>>>(h->part_s, h->part_q, tp, H / 64, h->cu + n_seqs, inv_h, c.ln_eps, h->st1_sum, h->st1_sq); }
         ARX_HIP_CHECK(hipGetLastError());
-        // hbuf = gelu(x1 W1^T + b1) ; y = hbuf W2^T + b2 + x1 ; x = LN(y)
-        ep = EpiParams{h->hbuf, F, L.b_fc1, nullptr, 0};
-        if ((rc = launch_gemm<EPI_BIAS_GELU>(ARX_K_GEMM_FC1, h->variant, h->x1, H, (const uint16_t*)L.w_fc1, H, T, F, H, ep, st)) != ARX_OK) return rc;
-        ep = EpiParams{h->y, H, L.b_fc2, h->x1, H};
-        if ((rc = launch_gemm<EPI_BIAS_RESID>(ARX_K_GEMM_FC2, h->variant, h->hbuf, F, (const uint16_t*)L.w_fc2, F, T, H, F, ep, st)) != ARX_OK) return rc;
+        // hbuf = gelu(LN1(y1) W1^T + b1)   (gamma1 folded into W1')
+        ep = EpiParams{h->hbuf, F, h->c_fc1[li], nullptr, 0};
+        ep.a_sum = h->st1_sum; ep.a_sq = h->st1_sq; ep.s_vec = h->s_fc1[li]; ep.inv_h = inv_h; ep.eps = c.ln_eps;
+        if ((rc = launch_gemm<EPI_LN_BIAS_GELU>(ARX_K_GEMM_FC1, h->variant, h->x1, H, h->wfc1_f[li], H, T, F, H, ep, st)) != ARX_OK) return rc;
+        // y2 = hbuf W2^T + b2 + LN1(y1)  -> x, statistics -> st2
+        ep = EpiParams{h->x, H, L.b_fc2, h->x1, H};
+        ep.r_sum = h->st1_sum; ep.r_sq = h->st1_sq; ep.r_gamma = L.ln1_g; ep.r_beta = L.ln1_b;
+        ep.o_sum = h->part_s; ep.o_sq = h->part_q; ep.o_ld = tp; ep.inv_h = inv_h; ep.eps = c.ln_eps;
+        if ((rc = launch_gemm<EPI_LNRESID_STATS>(ARX_K_GEMM_FC2, h->variant, h->hbuf, F, (const uint16_t*)L.w_fc2, F, T, H, F, ep, st)) != ARX_OK) return rc;
         { ProfScope ps(ARX_K_LAYERNORM, st);
-        layernorm_kernel<<<ln_grid, 256, 0, st>>>(h->y, h->x, L.ln2_g, L.ln2_b, h->cu + n_seqs, H, c.ln_eps); }
+          ln_finalize_kernel<<<cdiv(T, 256), 256, 0, st>>>(h->part_s, h->part_q, tp, H / 64, h->cu + n_seqs, inv_h, c.ln_eps, h->st2_sum, h->st2_sq); }
         ARX_HIP_CHECK(hipGetLastError());
-        if ((rc = tap(li + 1)) != ARX_OK) return rc;
+        if (h->tap_layer == li + 1 && h->tap) {       // parity tap: materialise LN2(y2) with the stand-alone kernel
+            layernorm_kernel<<<ln_grid, 256, 0, st>>>(h->x, h->tap, L.ln2_g, L.ln2_b, h->cu + n_seqs, H, c.ln_eps);
+            ARX_HIP_CHECK(hipGetLastError());
+        }
     }
-    ProfScope pps(ARX_K_POOL, st);
-    pool_norm_kernel<<<n_seqs, 256, 0, st>>>(h->x, h->cu, H, c.pool, normalize, out_f32, out_stride, (f16_t*)out_f16, out16_stride);
-    ARX_HIP_CHECK(hipGetLastError());
+    {
+        const arx_layer_weights& Ll = h->layers[c.layers - 1];
+        ProfScope pps(ARX_K_POOL, st);
+        pool_norm_kernel<<<n_seqs, 256, 0, st>>>(h->x, h->cu, H, c.pool, normalize, out_f32, out_stride, (f16_t*)out_f16, out16_stride,
+                                                 h->st2_sum, h->st2_sq, Ll.ln2_g, Ll.ln2_b, c.ln_eps);
+        ARX_HIP_CHECK(hipGetLastError());
+    }
     return ARX_OK;
 }
 

@@ -3,6 +3,8 @@
 // + L2 normalise.  Activations are token-PACKED: row t of every [T, *] buffer is token (t - cu[b]) of
 // sequence b, no padding rows between sequences.
 #pragma once
+#include <type_traits>
+
 #include "arx_common.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -348,6 +350,15 @@ template <int DH> struct AttnSmem2 {
     static __host__ __device__ int total(int Lk, bool has) { return 2 * kv_bytes(Lk) + (has ? 4 * (2 * Lk + 8) * 4 : 0); }
 };
 
+// bias copies: copy c lives at c*bias_stride + BIAS_OFF[c] floats; the offsets make the 16-lane ds_read_b128 groups
+// (lanes with q = 0-3,12-15,20-27 / 4-11,16-19,28-31) land on 16 distinct 16-B slots (brute-forced; 0 conflicts)
+template <int DH> struct AttnSmem3 {
+    static __host__ __device__ int kv_bytes(int Lk) { return Lk * DH * 2; }
+    static __host__ __device__ int bias_stride(int Lk) { return ((2 * Lk + 8 + 63) & ~63) + 64; }
+    static __host__ __device__ int total(int Lk, bool has) { return 2 * kv_bytes(Lk) + (has ? 4 * bias_stride(Lk) * 4 : 0); }
+};
+__device__ __forceinline__ int attn_bias_off(int c) { return c == 0 ? 0 : (c == 1 ? 20 : (c == 2 ? 36 : 52)); }
+
 template <int DH, bool HAS_BIAS, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
                                                                         const int32_t* __restrict__ cu,
@@ -358,6 +369,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     constexpr int RPB = 256 / (DH * 2);
     constexpr int KS = DH / 16;
     constexpr int DB = DH / 32;
+    constexpr int ROWB = DH * 2;                  // bytes per K / V row in LDS
+    constexpr int RPI = NT / CPR;                 // rows staged per pass of the block
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.z, h = blockIdx.y;
     const int t0 = cu[b];
@@ -366,34 +379,41 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     if (q0 >= L) return;
     const int Lk = (L + 31) & ~31;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t ld = 3 * (int64_t)H;
+    const uint32_t ld = 3u * (uint32_t)H;          // elements; in-sequence offsets stay 32-bit (rows < 512)
     const uint16_t* Qg = qkv + (int64_t)t0 * ld + h * DH;
     const uint16_t* Kg = Qg + H;
     const uint16_t* Vg = Qg + 2 * H;
     char* Ks = smem;
-    char* Vs = smem + AttnSmem2<DH>::kv_bytes(Lk);
-    float* Bs = reinterpret_cast<float*>(smem + 2 * AttnSmem2<DH>::kv_bytes(Lk));
-    const int bst = AttnSmem2<DH>::bias_stride(Lk);
+    char* Vs = smem + AttnSmem3<DH>::kv_bytes(Lk);
+    float* Bs = reinterpret_cast<float*>(smem + 2 * AttnSmem3<DH>::kv_bytes(Lk));
+    const int bst = AttnSmem3<DH>::bias_stride(Lk);
 
-    for (int cid = tid; cid < Lk * CPR; cid += NT) {
-        const int row = cid / CPR, pc = cid % CPR;
-        const int kc = pc ^ ((row / RPB) & (CPR - 1));
-        const int vc = (DH == 64) ? (pc ^ (((row >> 1) & 1) << 2)) : pc;
-        u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
-        if (row < L) {
-            kv = *reinterpret_cast<const u32x4*>(Kg + (int64_t)row * ld + kc * 8);
-            vv = *reinterpret_cast<const u32x4*>(Vg + (int64_t)row * ld + vc * 8);
+    {   // stage K (chunk ^ row swizzle) and V (chunk ^ 4*((row>>1)&1) for DH=64): this thread always owns physical
+        // chunk pc of rows r0, r0+RPI, ...; RPI is a multiple of 16, so both swizzle terms are per-thread constants
+        static_assert(RPI % 16 == 0, "staging pass must keep the swizzle terms constant per thread");
+        const int pc = tid % CPR, r0 = tid / CPR;
+        const int kc = pc ^ ((r0 / RPB) & (CPR - 1));
+        const int vc = (DH == 64) ? (pc ^ (((r0 >> 1) & 1) << 2)) : pc;
+        uint32_t gk = (uint32_t)r0 * ld + kc * 8, gv = (uint32_t)r0 * ld + vc * 8;
+        uint32_t lo = (uint32_t)tid * 16;
+        for (int row = r0; row < Lk; row += RPI, gk += RPI * ld, gv += RPI * ld, lo += NT * 16) {
+            u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
+            if (row < L) {
+                kv = *reinterpret_cast<const u32x4*>(Kg + gk);
+                vv = *reinterpret_cast<const u32x4*>(Vg + gv);
+            }
+            *reinterpret_cast<u32x4*>(Ks + lo) = kv;
+            *reinterpret_cast<u32x4*>(Vs + lo) = vv;
         }
-        *reinterpret_cast<u32x4*>(Ks + (int64_t)cid * 16) = kv;
-        *reinterpret_cast<u32x4*>(Vs + (int64_t)cid * 16) = vv;
     }
     if (HAS_BIAS) {
         const float* bt = bias_tbl + (int64_t)h * ARX_BIAS_ROW + ARX_BIAS_CENTER;
-        for (int i = tid; i < 4 * bst; i += NT) {
-            const int c = i / bst, j = i % bst;
+        const int span = 2 * Lk + 8;
+        for (int i = tid; i < 4 * span; i += NT) {
+            const int c = i / span, j = i - c * span;
             int d = j + c - Lk;
             d = d < -ARX_BIAS_CENTER ? -ARX_BIAS_CENTER : (d > ARX_BIAS_CENTER ? ARX_BIAS_CENTER : d);
-            Bs[i] = bt[d];
+            Bs[c * bst + attn_bias_off(c) + j] = bt[d];
         }
     }
     __syncthreads();
@@ -406,52 +426,55 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     bf16x8 qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
-        qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (int64_t)qc * ld + ks * 16 + hh * 8);
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (uint32_t)qc * ld + ks * 16 + hh * 8);
     f32x16 o[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    // running LDS pointers, advanced by one 32-key tile per iteration; every read below is base + constant
     const int bc = (4 - (qc & 3)) & 3;
-    const float* brow = Bs + bc * bst + (Lk - qc - bc);
+    const float* bptr = Bs + bc * bst + attn_bias_off(bc) + (Lk - qc - bc) + 4 * hh;
     const int krow_sw = ((ql / RPB) & (CPR - 1));
-    // transposing-read lane constants: 16-lane group g16, lane i in group: row q_ = i>>2, column quad p = i&3
+    const char* kptr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kptr[ks] = Ks + ql * ROWB + (((2 * ks + hh) ^ krow_sw) << 4);
     const int g16 = lane >> 4, q_ = (lane & 15) >> 2, p_ = lane & 3;
     const int vsw = (DH == 64) ? (((q_ >> 1) & 1) << 2) : 0;
-    int voff[DB];
+    const char* vptr[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d) {
-        const int col = 32 * d + 16 * (g16 & 1) + 4 * p_;                 // dh of this lane's 4-element run
-        voff[d] = (4 * hh + q_) * (DH * 2) + (((col >> 3) ^ vsw) << 4) + ((p_ & 1) << 3);
+        const int col = 32 * d + 16 * (g16 & 1) + 4 * p_;
+        vptr[d] = Vs + (4 * hh + q_) * ROWB + (((col >> 3) ^ vsw) << 4) + ((p_ & 1) << 3);
     }
-    const int nkt = Lk >> 5;
-    const bool ragged = (L & 31) != 0;
-    for (int kt = 0; kt < nkt; ++kt) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+    auto tile = [&](auto masked_tag, int kt) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        const char* krow = Ks + (int64_t)(kt * 32 + ql) * (DH * 2);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(krow + (((2 * ks + hh) ^ krow_sw) << 4));
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kptr[ks]);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
         }
-        const bool mask_tile = ragged && (kt == nkt - 1);
         float mx = -INFINITY;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-            const int kb = kt * 32 + 8 * g4 + 4 * hh;
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (HAS_BIAS) bv = *reinterpret_cast<const f32x4*>(brow + kb);
+            if (HAS_BIAS) bv = *reinterpret_cast<const f32x4*>(bptr + 8 * g4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = fmaf(s[g4 * 4 + e], scale_log2e, bv[e]);
-                if (mask_tile) v = (kb + e < L) ? v : -INFINITY;
+                if (MASKED) v = (kt * 32 + 8 * g4 + 4 * hh + e < L) ? v : -INFINITY;
                 s[g4 * 4 + e] = v;
-                mx = fmaxf(mx, v);
             }
         }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
         if (__any(m_new > m_run)) {
@@ -463,32 +486,42 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
             m_run = m_new;
         }
-        float rs = 0.f;
+        float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_run); rs += s[r]; }
-        l_run += rs;
+        for (int r = 0; r < 16; r += 2) {
+            s[r] = __builtin_amdgcn_exp2f(s[r] - m_run); s[r + 1] = __builtin_amdgcn_exp2f(s[r + 1] - m_run);
+            rs0 += s[r]; rs1 += s[r + 1];
+        }
+        l_run += rs0 + rs1;
         bf16x8 pf[2];
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[ss][e] = (bf16_t)s[8 * ss + e];
-        const char* vtile = Vs + (int64_t)(kt * 32) * (DH * 2);
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
-                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vtile + voff[d] + (16 * ss) * (DH * 2)));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vtile + voff[d] + (16 * ss + 8) * (DH * 2)));
-                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vptr[d] + (16 * ss) * ROWB));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vptr[d] + (16 * ss + 8) * ROWB));
                 s16x8 v8;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v8[e] = lo[e]; v8[4 + e] = hi[e]; }
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, v8);
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ss], o[d], 0, 0, 0);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf[ss], o[d], 0, 0, 0);
             }
         }
-    }
+        // advance to the next 32-key tile
+        bptr += 32;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kptr[ks] += 32 * ROWB;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) vptr[d] += 32 * ROWB;
+    };
+    const int nkt = Lk >> 5;
+    const int nfull = (L & 31) ? nkt - 1 : nkt;           // tiles with no masked key
+    for (int kt = 0; kt < nfull; ++kt) tile(std::false_type{}, kt);
+    if (nfull < nkt) tile(std::true_type{}, nkt - 1);
+
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     if (q < L) {
@@ -511,7 +544,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
 __global__ __launch_bounds__(256) void pool_norm_kernel(const uint16_t* __restrict__ x, const int32_t* __restrict__ cu,
                                                          int H, int pool_mode, int normalize,
                                                          float* __restrict__ out32, int64_t ld32,
-                                                         f16_t* __restrict__ out16, int64_t ld16) {
+                                                         f16_t* __restrict__ out16, int64_t ld16,
+                                                         const float* __restrict__ ln_sum, const float* __restrict__ ln_sq,
+                                                         const float* __restrict__ ln_g, const float* __restrict__ ln_b, float eps) {
+    // ln_sum != null: x holds the PRE-LayerNorm sums of the last layer; the row LayerNorm is applied while pooling:
+    //   mean_t LN(y_t) = gamma o mean_t((y_t - mu_t) rstd_t) + beta
     __shared__ float acc_s[4][1024];
     __shared__ float red[4];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -525,6 +562,8 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const uint16_t* __restri
     const int nrows = (pool_mode == ARX_POOL_CLS) ? (L > 0 ? 1 : 0) : L;
     for (int r = w; r < nrows; r += 4) {
         const uint16_t* in = x + (int64_t)(t0 + r) * H;
+        float mu = 0.f, rs = 1.f;
+        if (ln_sum) { mu = ln_sum[t0 + r]; rs = ln_sq[t0 + r]; }      // row mean / rstd from ln_finalize_kernel
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int ch = lane + 64 * c;
@@ -534,7 +573,7 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const uint16_t* __restri
                 for (int e = 0; e < 4; ++e) {
                     float lo, hi;
                     unpack_bf16x2(q[e], lo, hi);
-                    a[c][2 * e] += lo; a[c][2 * e + 1] += hi;
+                    a[c][2 * e] += (lo - mu) * rs; a[c][2 * e + 1] += (hi - mu) * rs;
                 }
             }
         }
@@ -547,7 +586,6 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const uint16_t* __restri
             for (int e = 0; e < 8; ++e) acc_s[w][ch * 8 + e] = a[c][e];
     }
     __syncthreads();
-    // thread tid owns columns tid, tid+256, ... (H <= 1024)
     float v[4];
     float sq = 0.f;
     const float denom = (pool_mode == ARX_POOL_CLS) ? 1.0f : fmaxf((float)L, 1e-9f);
@@ -557,6 +595,7 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const uint16_t* __restri
         v[c] = 0.f;
         if (col < H) {
             v[c] = (acc_s[0][col] + acc_s[1][col] + acc_s[2][col] + acc_s[3][col]) / denom;
+            if (ln_sum && L > 0) v[c] = fmaf(v[c], ln_g[col], ln_b[col]);
             sq += v[c] * v[c];
         }
     }
@@ -574,6 +613,40 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const uint16_t* __restri
             if (out16) out16[(int64_t)b * ld16 + col] = (f16_t)y;
         }
     }
+}
+
+// Row statistics from the producers' partial slabs, added in fixed order: mean[m], rstd[m].
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int64_t ld,
+                                                           int nparts, const int32_t* __restrict__ n_rows_ptr, float inv_h, float eps,
+                                                           float* __restrict__ mean, float* __restrict__ rstd) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= *n_rows_ptr) return;
+    float s = 0.f, q = 0.f;
+    for (int p = 0; p < nparts; ++p) { s += ps[p * ld + m]; q += pq[p * ld + m]; }
+    const float mu = s * inv_h;
+    mean[m] = mu;
+    rstd[m] = rsqrtf(fmaxf(q * inv_h - mu * mu, 0.f) + eps);
+}
+
+// Fold a LayerNorm into the linear layer that consumes it (one wave per output row n):
+//   W'[n][k] = bf16(W[n][k] * gamma[k]);  s[n] = sum_k W'[n][k];  c[n] = bias[n] + sum_k beta[k] * W[n][k]
+__global__ __launch_bounds__(256) void fold_ln_kernel(const uint16_t* __restrict__ W, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ bias,
+                                                       uint16_t* __restrict__ Wf, float* __restrict__ s, float* __restrict__ c,
+                                                       int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float ss = 0.f, cc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = bf16_bits_to_f32(W[(int64_t)n * K + k]);
+        const bf16_t wf = (bf16_t)(w * gamma[k]);
+        Wf[(int64_t)n * K + k] = __builtin_bit_cast(uint16_t, wf);
+        ss += (float)wf;
+        cc = fmaf(beta[k], w, cc);
+    }
+    ss = wave_sum(ss); cc = wave_sum(cc);
+    if (lane == 0) { s[n] = ss; c[n] = bias[n] + cc; }
 }
 
 // bf16 [n, H] -> f32 (debug tap)

@@ -154,15 +154,39 @@ struct GemmMainloop {
 // ---- epilogues --------------------------------------------------------------------------------
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2 };
+// LayerNorm is never run as a kernel inside the layer loop: a producer GEMM (modes 5/6) stores the PRE-LN sum y and
+// writes per-row partial (sum, sum of squares) of each 64-column slice to a slab (no atomics: a tiny finalize kernel
+// adds the N/64 partials in fixed order, so results stay bit-reproducible); the consumer GEMM (modes 3/4) takes y as its A
+// operand with gamma folded into the weights (W' = W o gamma, s_n = sum_k W'[n][k], c_n = b_n + sum_k beta_k W[n][k]):
+//     LN(y) W^T + b = rstd_m * (y W'^T - mean_m * s_n) + c_n
+// and a residual that is itself a LayerNorm output is rebuilt on the fly from y, the row statistics, gamma, beta.
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2,
+       EPI_LN_BIAS = 3,            // out = rstd*(acc - mean*s) + c
+       EPI_LN_BIAS_GELU = 4,       // out = gelu(rstd*(acc - mean*s) + c)
+       EPI_RESID_STATS = 5,        // out = acc + bias + resid ; row stats of out
+       EPI_LNRESID_STATS = 6 };    // out = acc + bias + LN(resid) ; row stats of out
 
 struct EpiParams {
     uint16_t* out;          // bf16 [M, ldc]
     int64_t ldc;
-    const float* bias;      // [N]
+    const float* bias;      // [N]  (modes 3/4: the folded c vector)
     const uint16_t* resid;  // bf16 [M, ldr] or null
     int64_t ldr;
+    // LayerNorm plumbing (modes 3..6)
+    const float* a_sum = nullptr;   // [M] row MEAN of the A operand's source rows (modes 3/4)
+    const float* a_sq = nullptr;    // [M] row RSTD
+    const float* s_vec = nullptr;   // [N] s_n (modes 3/4)
+    const float* r_sum = nullptr;   // [M] row MEAN / RSTD of the residual's source rows (mode 6)
+    const float* r_sq = nullptr;
+    const float* r_gamma = nullptr; // [N] LayerNorm affine of the residual (mode 6)
+    const float* r_beta = nullptr;
+    float* o_sum = nullptr;         // [N/64][o_ld] partial row sums of the output, one slab row per 64-column slice (modes 5/6)
+    float* o_sq = nullptr;          // [N/64][o_ld] partial sums of squares
+    int64_t o_ld = 0;
+    float inv_h = 0.f, eps = 0.f;
 };
+
+
 
 template <int MODE, int NI, int MI>
 __device__ __forceinline__ void epilogue_store(const f32x4 (&acc)[NI][MI], const EpiParams& p, int m_base, int n_base,
@@ -328,12 +352,30 @@ template <int MODE, int NI, int MI>
 __device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], const EpiParams& p, int m_base, int n_base,
                                                   int lane, int M, int N) {
     static_assert(NI % 2 == 0, "pairs of 16-column blocks");
+    constexpr bool LN_IN = (MODE == EPI_LN_BIAS || MODE == EPI_LN_BIAS_GELU);
+    constexpr bool STATS = (MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS);
+    constexpr bool RESID = (MODE == EPI_BIAS_RESID || STATS);
     const int mq = lane & 15, q = lane >> 4, odd = q & 1;
+    float a_mean[MI], a_rstd[MI], r_mean[MI], r_rstd[MI], st_s[MI], st_q[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        int m = m_base + i * 16 + mq;
+        m = m < M ? m : M - 1;
+        a_mean[i] = 0.f; a_rstd[i] = 1.f; r_mean[i] = 0.f; r_rstd[i] = 1.f; st_s[i] = 0.f; st_q[i] = 0.f;
+        if constexpr (LN_IN) { a_mean[i] = p.a_sum[m]; a_rstd[i] = p.a_sq[m]; }
+        if constexpr (MODE == EPI_LNRESID_STATS) { r_mean[i] = p.r_sum[m]; r_rstd[i] = p.r_sq[m]; }
+    }
 #pragma unroll
     for (int jp = 0; jp < NI / 2; ++jp) {
         const int n = n_base + (2 * jp + odd) * 16 + (q >> 1) * 8;
-        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
-        if (n < N) { b0 = *reinterpret_cast<const f32x4*>(p.bias + n); b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4); }
+        const int nc = n < N ? n : 0;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + nc), b1 = *reinterpret_cast<const f32x4*>(p.bias + nc + 4);
+        f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, g0 = s0, g1 = s0, e0 = s0, e1 = s0;
+        if constexpr (LN_IN) { s0 = *reinterpret_cast<const f32x4*>(p.s_vec + nc); s1 = *reinterpret_cast<const f32x4*>(p.s_vec + nc + 4); }
+        if constexpr (MODE == EPI_LNRESID_STATS) {
+            g0 = *reinterpret_cast<const f32x4*>(p.r_gamma + nc); g1 = *reinterpret_cast<const f32x4*>(p.r_gamma + nc + 4);
+            e0 = *reinterpret_cast<const f32x4*>(p.r_beta + nc); e1 = *reinterpret_cast<const f32x4*>(p.r_beta + nc + 4);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const f32x4 keep = odd ? acc[2 * jp + 1][i] : acc[2 * jp][i];
@@ -345,21 +387,60 @@ __device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], co
             const int m = m_base + i * 16 + mq;
             if (m >= M || n >= N) continue;
             float v[8];
+            if constexpr (LN_IN) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = lo[r] + b0[r]; v[4 + r] = hi[r] + b1[r]; }
-            if constexpr (MODE == EPI_BIAS_GELU) {
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = fmaf(a_rstd[i], lo[r] - a_mean[i] * s0[r], b0[r]);
+                    v[4 + r] = fmaf(a_rstd[i], hi[r] - a_mean[i] * s1[r], b1[r]);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = lo[r] + b0[r]; v[4 + r] = hi[r] + b1[r]; }
+            }
+            if constexpr (MODE == EPI_BIAS_GELU || MODE == EPI_LN_BIAS_GELU) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
             }
-            if constexpr (MODE == EPI_BIAS_RESID) {
+            if constexpr (RESID) {
                 const u32x4 rr = *reinterpret_cast<const u32x4*>(p.resid + (int64_t)m * p.ldr + n);
+                float ra[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { float a, b; unpack_bf16x2(rr[r], a, b); v[2 * r] += a; v[2 * r + 1] += b; }
+                for (int r = 0; r < 4; ++r) unpack_bf16x2(rr[r], ra[2 * r], ra[2 * r + 1]);
+                if constexpr (MODE == EPI_LNRESID_STATS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ra[r] = fmaf((ra[r] - r_mean[i]) * r_rstd[i], g0[r], e0[r]);
+                        ra[4 + r] = fmaf((ra[4 + r] - r_mean[i]) * r_rstd[i], g1[r], e1[r]);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += ra[r];
             }
             u32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = pack_bf16x2(v[2 * r], v[2 * r + 1]);
             *reinterpret_cast<u32x4*>(p.out + (int64_t)m * p.ldc + n) = o;
+            if constexpr (STATS) {
+                // statistics of the bf16-ROUNDED values (what the consumers will read back)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x0, x1;
+                    unpack_bf16x2(o[r], x0, x1);
+                    st_s[i] += x0 + x1;
+                    st_q[i] = fmaf(x0, x0, fmaf(x1, x1, st_q[i]));
+                }
+            }
+        }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            float a = st_s[i], b = st_q[i];
+            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+            const int m = m_base + i * 16 + mq;
+            const int64_t part = n_base >> 6;                    // this wave's 64-column slice
+            if (q == 0 && m < M && n_base < N) { p.o_sum[part * p.o_ld + m] = a; p.o_sq[part * p.o_ld + m] = b; }
         }
     }
 }
@@ -397,3 +478,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_v0e2_kernel(const bf16_t* _
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     epilogue_store_v2<MODE, ML::NI, ML::MI>(acc, ep, m0 + (wid / WN) * ML::TM, n0 + (wid % WN) * ML::TN, lane, M, N);
 }
+
+
+// (A persistent one-block-per-CU variant with cross-tile prefetch was measured 5-15 % SLOWER than the plain
+//  grid on all four encoder shapes and was removed; DESIGN.md §4 keeps the numbers.)
+
+// (A 128 x 768 "row-block" GEMM with the residual + LayerNorm fused into its epilogue — every A element staged
+//  once chip-wide, no pre-LN tensor in HBM — was built and measured: its 48 KB-per-half-step W stream left only
+//  2 x BK=32 LDS stages and it ran 674 TF on FFN-2 / 398 TF on the O projection, slower than the 256^2 kernel
+//  plus the separate LayerNorm kernel (1.40 / 0.65 ms vs 1.84 / 0.78 ms); removed.  DESIGN.md §4.)

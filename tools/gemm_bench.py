@@ -73,3 +73,4 @@ for name, N, K, mode in shapes:
     for v in variants:
         t = np.median(res[v]["t"]); tm = min(res[v]["t"])
         print(f"{name:6s} N={N:5d} K={K:5d} mode{mode} v{v}: {t:7.3f} ms (min {tm:.3f})  {flops/t/1e9:7.1f} TF   maxerr {res[v]['err']:.4f} nan={res[v]['nan']}")
+
