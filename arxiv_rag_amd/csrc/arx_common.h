@@ -50,10 +50,12 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // ---- device helpers ---------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
 
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) at -O3
-    bf16_t a = (bf16_t)lo, b = (bf16_t)hi;
-    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+    // vector convert: ONE v_cvt_pk_bf16_f32 (RNE, NaN-preserving) writing both halves of the dword
+    const f32x2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2));
 }
 
 __device__ __forceinline__ void unpack_bf16x2(uint32_t v, float& lo, float& hi) {

@@ -348,19 +348,26 @@ __device__ __forceinline__ float gelu_fast(float v) {
     return 0.5f * v + 0.5f * fabsf(v) * erf_abs;              // 0.5 v (1 + sign(v) erf(|v|/sqrt2))
 }
 
-template <int MODE, int NI, int MI>
-__device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], const EpiParams& p, int m_base, int n_base,
-                                                  int lane, int M, int N) {
+// Lane exchange: v_permlane16_swap(X, Y) swaps the odd 16-lane rows of X with the even rows of Y.  With X = this
+// lane's 4 columns of block 2jp and Y = of block 2jp+1, afterwards (lo, hi) = (X', Y') are 8 CONSECUTIVE columns in
+// every lane: even rows hold block 2jp columns 8*(q>>1).., odd rows block 2jp+1 — one instruction per register
+// pair, no selects (checked against torch on the GPU box by tools/gemm_bench.py and tests/test_gpu_parity.py).
+template <int MODE, bool CHECK, int NI, int MI>
+__device__ __forceinline__ void epilogue_store_v2_impl(const f32x4 (&acc)[NI][MI], const EpiParams& p, int m_base, int n_base,
+                                                       int lane, int M, int N) {
     static_assert(NI % 2 == 0, "pairs of 16-column blocks");
     constexpr bool LN_IN = (MODE == EPI_LN_BIAS || MODE == EPI_LN_BIAS_GELU);
     constexpr bool STATS = (MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS);
     constexpr bool RESID = (MODE == EPI_BIAS_RESID || STATS);
     const int mq = lane & 15, q = lane >> 4, odd = q & 1;
     float a_mean[MI], a_rstd[MI], r_mean[MI], r_rstd[MI], st_s[MI], st_q[MI];
+    uint32_t orow[MI], rrow[MI];          // element offsets (M * ld < 2^32 for every encoder shape)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         int m = m_base + i * 16 + mq;
-        m = m < M ? m : M - 1;
+        if (CHECK) m = m < M ? m : M - 1;
+        orow[i] = (uint32_t)m * (uint32_t)p.ldc;
+        rrow[i] = (uint32_t)m * (uint32_t)p.ldr;
         a_mean[i] = 0.f; a_rstd[i] = 1.f; r_mean[i] = 0.f; r_rstd[i] = 1.f; st_s[i] = 0.f; st_q[i] = 0.f;
         if constexpr (LN_IN) { a_mean[i] = p.a_sum[m]; a_rstd[i] = p.a_sq[m]; }
         if constexpr (MODE == EPI_LNRESID_STATS) { r_mean[i] = p.r_sum[m]; r_rstd[i] = p.r_sq[m]; }
@@ -368,7 +375,7 @@ __device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], co
 #pragma unroll
     for (int jp = 0; jp < NI / 2; ++jp) {
         const int n = n_base + (2 * jp + odd) * 16 + (q >> 1) * 8;
-        const int nc = n < N ? n : 0;
+        const int nc = (!CHECK || n < N) ? n : 0;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + nc), b1 = *reinterpret_cast<const f32x4*>(p.bias + nc + 4);
         f32x4 s0 = f32x4{0.f, 0.f, 0.f, 0.f}, s1 = s0, g0 = s0, g1 = s0, e0 = s0, e1 = s0;
         if constexpr (LN_IN) { s0 = *reinterpret_cast<const f32x4*>(p.s_vec + nc); s1 = *reinterpret_cast<const f32x4*>(p.s_vec + nc + 4); }
@@ -378,14 +385,14 @@ __device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], co
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const f32x4 keep = odd ? acc[2 * jp + 1][i] : acc[2 * jp][i];
-            const f32x4 send = odd ? acc[2 * jp][i] : acc[2 * jp + 1][i];
-            f32x4 recv;
+            f32x4 lo, hi;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) recv[r] = __shfl_xor(send[r], 16);
-            const f32x4 lo = odd ? recv : keep, hi = odd ? keep : recv;
-            const int m = m_base + i * 16 + mq;
-            if (m >= M || n >= N) continue;
+            for (int r = 0; r < 4; ++r) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * jp][i][r]),
+                                                                 __float_as_uint(acc[2 * jp + 1][i][r]), false, false);
+                lo[r] = __uint_as_float(sw[0]); hi[r] = __uint_as_float(sw[1]);
+            }
+            if (CHECK && (m_base + i * 16 + mq >= M || n >= N)) continue;
             float v[8];
             if constexpr (LN_IN) {
 #pragma unroll
@@ -402,7 +409,7 @@ __device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], co
                 for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
             }
             if constexpr (RESID) {
-                const u32x4 rr = *reinterpret_cast<const u32x4*>(p.resid + (int64_t)m * p.ldr + n);
+                const u32x4 rr = *reinterpret_cast<const u32x4*>(p.resid + rrow[i] + n);
                 float ra[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) unpack_bf16x2(rr[r], ra[2 * r], ra[2 * r + 1]);
@@ -419,7 +426,7 @@ __device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], co
             u32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = pack_bf16x2(v[2 * r], v[2 * r + 1]);
-            *reinterpret_cast<u32x4*>(p.out + (int64_t)m * p.ldc + n) = o;
+            *reinterpret_cast<u32x4*>(p.out + orow[i] + n) = o;
             if constexpr (STATS) {
                 // statistics of the bf16-ROUNDED values (what the consumers will read back)
 #pragma unroll
@@ -443,6 +450,14 @@ __device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], co
             if (q == 0 && m < M && n_base < N) { p.o_sum[part * p.o_ld + m] = a; p.o_sq[part * p.o_ld + m] = b; }
         }
     }
+}
+
+template <int MODE, int NI, int MI>
+__device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], const EpiParams& p, int m_base, int n_base,
+                                                  int lane, int M, int N) {
+    // interior wave tiles (the common case) skip every bounds test
+    if (m_base + MI * 16 <= M && n_base + NI * 16 <= N) epilogue_store_v2_impl<MODE, false, NI, MI>(acc, p, m_base, n_base, lane, M, N);
+    else epilogue_store_v2_impl<MODE, true, NI, MI>(acc, p, m_base, n_base, lane, M, N);
 }
 
 template <int BM, int BN, int WM, int WN, int SLOTS, int MODE>
