@@ -274,7 +274,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else static_assert(N < 0, "add the vmcnt literal");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int SLOTS>
+template <typename T, int BM, int BN, int WM, int WN, int SLOTS, int OPT = 0>
 struct GemmRing {
     static constexpr int NT = WM * WN * 64;
     static constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
@@ -318,17 +318,26 @@ struct GemmRing {
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();          // everyone's part of h landed; everyone done reading slot (h-1)
             __builtin_amdgcn_sched_barrier(0);
-            if (h + DEPTH < nh) issue(Ag, lda, M, Wg, ldw, N, m0, n0, h + DEPTH, smem, tid);
+            if (!(OPT & 4) && h + DEPTH < nh) issue(Ag, lda, M, Wg, ldw, N, m0, n0, h + DEPTH, smem, tid);
             const char* slot = smem + (h % SLOTS) * SLOT_BYTES;
             vec af[MI], wf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec*>(slot + a_base + i * 1024);
 #pragma unroll
             for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const vec*>(slot + w_base + j * 1024);
+            if constexpr (OPT & 8) {
 #pragma unroll
-            for (int j = 0; j < NI; ++j)
+                for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
-                for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<T>::mma(wf[j], af[i], acc[j][i]);
+                for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(wf[j]));
+            } else {
+                if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<T>::mma(wf[j], af[i], acc[j][i]);
+                if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(0);
+            }
         }
     }
 };
@@ -383,6 +392,14 @@ __device__ __forceinline__ void epilogue_store_v2_impl(const f32x4 (&acc)[NI][MI
             g0 = *reinterpret_cast<const f32x4*>(p.r_gamma + nc); g1 = *reinterpret_cast<const f32x4*>(p.r_gamma + nc + 4);
             e0 = *reinterpret_cast<const f32x4*>(p.r_beta + nc); e1 = *reinterpret_cast<const f32x4*>(p.r_beta + nc + 4);
         }
+        // all residual vectors of this column pair are requested BEFORE any of them is consumed: the loads overlap
+        // each other and the exchange below instead of paying one L2 round trip per (row block) in sequence
+        u32x4 rres[MI];
+        if constexpr (RESID) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                if (!CHECK || (m_base + i * 16 + mq < M && n < N)) rres[i] = *reinterpret_cast<const u32x4*>(p.resid + rrow[i] + n);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             f32x4 lo, hi;
@@ -409,7 +426,7 @@ __device__ __forceinline__ void epilogue_store_v2_impl(const f32x4 (&acc)[NI][MI
                 for (int r = 0; r < 8; ++r) v[r] = gelu_fast(v[r]);
             }
             if constexpr (RESID) {
-                const u32x4 rr = *reinterpret_cast<const u32x4*>(p.resid + rrow[i] + n);
+                const u32x4 rr = rres[i];
                 float ra[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) unpack_bf16x2(rr[r], ra[2 * r], ra[2 * r + 1]);
@@ -460,12 +477,12 @@ __device__ __forceinline__ void epilogue_store_v2(const f32x4 (&acc)[NI][MI], co
     else epilogue_store_v2_impl<MODE, true, NI, MI>(acc, p, m_base, n_base, lane, M, N);
 }
 
-template <int BM, int BN, int WM, int WN, int SLOTS, int MODE>
+template <int BM, int BN, int WM, int WN, int SLOTS, int MODE, int OPT = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_ring_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                                    const bf16_t* __restrict__ W, int64_t ldw,
                                                                    int M, int N, int K, int tiles_m, int tiles_n,
                                                                    EpiParams ep) {
-    using ML = GemmRing<bf16_t, BM, BN, WM, WN, SLOTS>;
+    using ML = GemmRing<bf16_t, BM, BN, WM, WN, SLOTS, OPT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
     const int tile_m = t / tiles_n, tile_n = t % tiles_n;
