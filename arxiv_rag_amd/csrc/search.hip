@@ -131,37 +131,35 @@ __global__ __launch_bounds__(256) void select_groups_kernel(const float* __restr
     }
 }
 
-// block-wide argmax over (score desc, id asc); ids < 0 are empty slots. Returns winner index in LDS arrays.
-template <int NT>
-__device__ __forceinline__ int block_argbest(const float* s, const int64_t* id, int n, int tid, float* red_s,
-                                             int64_t* red_i, int* red_p) {
-    float bs = -INFINITY; int64_t bi = INT64_MAX; int bp = -1;
-    for (int i = tid; i < n; i += NT) {
-        const float v = s[i]; const int64_t vi = id[i];
-        if (vi < 0) continue;
-        if (bp < 0 || v > bs || (v == bs && vi < bi)) { bs = v; bi = vi; bp = i; }
-    }
+// Wave-synchronous top-k: every lane holds R candidates in registers; k rounds of (lane-local best, 6-step
+// shuffle arg-best, winner retires its candidate).  No LDS, no block barrier.  Order: score desc, id asc; id < 0 = empty.
+template <int R>
+__device__ __forceinline__ void wave_topk(float (&s)[R], int64_t (&id)[R], int k, int lane, float* out_s, int64_t* out_i) {
+    for (int r = 0; r < k; ++r) {
+        float bs = -INFINITY; int64_t bi = INT64_MAX; int bj = -1;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float os = __shfl_xor(bs, o); const int64_t oi = __shfl_xor(bi, o); const int op = __shfl_xor(bp, o);
-        if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
-    }
-    const int w = tid >> 6;
-    if ((tid & 63) == 0) { red_s[w] = bs; red_i[w] = bi; red_p[w] = bp; }
-    __syncthreads();
-    bs = red_s[0]; bi = red_i[0]; bp = red_p[0];
+        for (int j = 0; j < R; ++j)
+            if (id[j] >= 0 && (bj < 0 || s[j] > bs || (s[j] == bs && id[j] < bi))) { bs = s[j]; bi = id[j]; bj = j; }
+        float ws = bs; int64_t wi = bi; int wl = bj >= 0 ? lane : -1;
 #pragma unroll
-    for (int k = 1; k < NT / 64; ++k) {
-        const float os = red_s[k]; const int64_t oi = red_i[k]; const int op = red_p[k];
-        if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float os = __shfl_xor(ws, o); const int64_t oi = __shfl_xor(wi, o); const int ol = __shfl_xor(wl, o);
+            if (ol >= 0 && (wl < 0 || os > ws || (os == ws && oi < wi))) { ws = os; wi = oi; wl = ol; }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (wl == lane && j == bj) id[j] = -1;
+        if (lane == 0) { out_s[r] = wl >= 0 ? ws : -INFINITY; out_i[r] = wl >= 0 ? wi : -1; }
     }
-    __syncthreads();
-    return bp;
 }
 
-// pass B1 stage 2 + pass B2: one block of 16 waves per query.  Wave w rescoring group w (, w+16, ...):
-// 16 lanes per corpus row, 4 rows per step, query row staged in LDS.
+// pass B1 stage 2 + pass B2: one block of 16 waves per query; 4 block barriers in total.
+//   (1) each wave reduces its slice of the nslices*K partial super-groups to K, wave 0 reduces 16*K -> K
+//   (2) wave 0 expands to K*SUPER groups (their gmax), reduces to the K best groups
+//   (3) wave w rescoring group w (, w+16, ...): 8 lanes per corpus row, query row staged in LDS; keeps its top-k
+//   (4) wave 0 reduces 16*k -> k and writes the result
 #define RS_NT 1024
+#define RS_NW (RS_NT / 64)
 template <int K>
 __global__ __launch_bounds__(RS_NT) void rescore_kernel(const float* __restrict__ part_s, const int32_t* __restrict__ part_g,
                                                          int nslices, int64_t ldg, const float* __restrict__ gmax,
@@ -170,73 +168,135 @@ __global__ __launch_bounds__(RS_NT) void rescore_kernel(const float* __restrict_
                                                          float* __restrict__ out_s, int64_t* __restrict__ out_i,
                                                          int64_t idx_base) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float red_s[RS_NT / 64]; __shared__ int64_t red_i[RS_NT / 64]; __shared__ int red_p[RS_NT / 64];
+    constexpr int R1 = (256 * K + RS_NT - 1) / RS_NT;        // candidates per lane in stage (1): nslices <= 256
+    constexpr int KK = K > KMAX ? K : KMAX;
+    __shared__ float w_s[RS_NW][KK];
+    __shared__ int64_t w_i[RS_NW][KK];
     __shared__ int32_t sel_g[K];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int ncand = nslices * K;
-    const int nmax = ncand > K * GROUP_ROWS ? ncand : K * GROUP_ROWS;
-    static_assert(SUPER <= GROUP_ROWS, "expanded candidates must fit the score buffer");
-    float* cs = reinterpret_cast<float*>(smem);                                     // [nmax]
-    int64_t* ci = reinterpret_cast<int64_t*>(smem + (((size_t)nmax * 4 + 15) & ~(size_t)15));   // [nmax]
-    f16_t* qs = reinterpret_cast<f16_t*>(reinterpret_cast<char*>(ci) + (size_t)nmax * 8);        // [D]
-    for (int i = tid; i < ncand; i += RS_NT) {
-        const int sl = i / K, p = i % K;
-        const int64_t o = ((int64_t)sl * ldg + q) * K + p;
-        cs[i] = part_s[o]; ci[i] = part_g[o];
-    }
+    f16_t* qs = reinterpret_cast<f16_t*>(smem);               // [D] query row
+    float* gs = reinterpret_cast<float*>(smem + (((size_t)D * 2 + 15) & ~(size_t)15));          // [K*64] row scores
+    int64_t* gi_ = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(gs) + K * GROUP_ROWS * 4);  // [K*64] row ids
     for (int i = tid; i < (D >> 3); i += RS_NT)
         reinterpret_cast<u32x4*>(qs)[i] = reinterpret_cast<const u32x4*>(Q + (int64_t)q * D)[i];
+    // (1) partial super-groups -> K best
+    {
+        const int ncand = nslices * K;
+        float s[R1]; int64_t id[R1];
+#pragma unroll
+        for (int j = 0; j < R1; ++j) {
+            const int i = (w * R1 + j) * 64 + lane;            // wave w owns a contiguous range
+            s[j] = -INFINITY; id[j] = -1;
+            if (i < ncand) {
+                const int sl = i / K, p = i - sl * K;
+                const int64_t o = ((int64_t)sl * ldg + q) * K + p;
+                s[j] = part_s[o]; id[j] = part_g[o];
+            }
+        }
+        wave_topk<R1>(s, id, K, lane, w_s[w], w_i[w]);
+    }
     __syncthreads();
-    for (int r = 0; r < K; ++r) {                                    // top-K super-groups
-        const int bp = block_argbest<RS_NT>(cs, ci, ncand, tid, red_s, red_i, red_p);
-        if (tid == 0) { sel_g[r] = bp >= 0 ? (int32_t)ci[bp] : -1; if (bp >= 0) ci[bp] = -1; }
-        __syncthreads();
-    }
-    for (int i = tid; i < K * SUPER; i += RS_NT) {                   // expand to their K*SUPER groups
-        const int sg = sel_g[i / SUPER];
-        const int64_t g = (int64_t)sg * SUPER + (i % SUPER);
-        const bool ok = sg >= 0 && g < n_groups;
-        cs[i] = ok ? gmax[g * ldg + q] : -INFINITY;
-        ci[i] = ok ? g : -1;
+    if (w == 0) {
+        constexpr int R2 = (RS_NW * K + 63) / 64;
+        float s[R2]; int64_t id[R2];
+#pragma unroll
+        for (int j = 0; j < R2; ++j) {
+            const int i = j * 64 + lane;
+            s[j] = i < RS_NW * K ? w_s[i / K][i % K] : -INFINITY;
+            id[j] = i < RS_NW * K ? w_i[i / K][i % K] : -1;
+        }
+        wave_topk<R2>(s, id, K, lane, gs, gi_);                // K best super-groups -> gs/gi_[0..K)
+        // (2) expand to K*SUPER groups, reduce to the K best groups
+        constexpr int R3 = (K * SUPER + 63) / 64;
+        float s3[R3]; int64_t id3[R3];
+#pragma unroll
+        for (int j = 0; j < R3; ++j) {
+            const int i = j * 64 + lane;
+            s3[j] = -INFINITY; id3[j] = -1;
+            if (i < K * SUPER) {
+                const int64_t sg = gi_[i / SUPER];
+                const int64_t g = sg * SUPER + (i % SUPER);
+                if (sg >= 0 && g < n_groups) { s3[j] = gmax[g * ldg + q]; id3[j] = g; }
+            }
+        }
+        wave_topk<R3>(s3, id3, K, lane, w_s[0], w_i[0]);
+        if (lane < K) sel_g[lane] = (int32_t)w_i[0][lane];
     }
     __syncthreads();
-    for (int r = 0; r < K; ++r) {                                    // top-K groups
-        const int bp = block_argbest<RS_NT>(cs, ci, K * SUPER, tid, red_s, red_i, red_p);
-        if (tid == 0) { sel_g[r] = bp >= 0 ? (int32_t)ci[bp] : -1; if (bp >= 0) ci[bp] = -1; }
-        __syncthreads();
-    }
-    // exact scores of the K selected groups
-    const int nch = D >> 3, l16 = lane & 15, rsub = lane >> 4;
-    for (int gi = w; gi < K; gi += RS_NT / 64) {
-        const int gsel = sel_g[gi];
-#pragma unroll 2
-        for (int r4 = 0; r4 < GROUP_ROWS; r4 += 4) {
-            const int rr = r4 + rsub;
+    // (3) exact scores: 8 lanes per corpus row, 8 rows per step, several independent 16-B loads in flight per lane
+    const int nch = D >> 3, l8 = lane & 7, rsub = lane >> 3;
+    constexpr int GPW = (K + RS_NW - 1) / RS_NW;              // groups per wave
+#pragma unroll
+    for (int gq = 0; gq < GPW; ++gq) {
+        const int gidx = w + gq * RS_NW;
+        if (gidx >= K) continue;
+        const int gsel = sel_g[gidx];
+        for (int r8 = 0; r8 < GROUP_ROWS; r8 += 8) {
+            const int rr = r8 + rsub;
             const int64_t row = (int64_t)gsel * GROUP_ROWS + rr;
             const bool ok = gsel >= 0 && row < n_rows;
-            float a = 0.f;
+            float a0 = 0.f, a1 = 0.f;
             if (ok) {
                 const f16_t* crow = C + row * D;
-                for (int ch = l16; ch < nch; ch += 16) {
+                int ch = l8;
+#pragma unroll 1
+                for (; ch + 24 < nch; ch += 32) {
+                    f16x8 cv[4], qq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) cv[u] = *reinterpret_cast<const f16x8*>(crow + (ch + 8 * u) * 8);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) qq[u] = *reinterpret_cast<const f16x8*>(qs + (ch + 8 * u) * 8);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            a0 = fmaf((float)cv[u][e], (float)qq[u][e], a0);
+                            a1 = fmaf((float)cv[u][e + 1], (float)qq[u][e + 1], a1);
+                        }
+                }
+                for (; ch < nch; ch += 8) {
                     const f16x8 cv = *reinterpret_cast<const f16x8*>(crow + ch * 8);
                     const f16x8 qq = *reinterpret_cast<const f16x8*>(qs + ch * 8);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a = fmaf((float)cv[e], (float)qq[e], a);
+                    for (int e = 0; e < 8; e += 2) {
+                        a0 = fmaf((float)cv[e], (float)qq[e], a0);
+                        a1 = fmaf((float)cv[e + 1], (float)qq[e + 1], a1);
+                    }
                 }
             }
-            a += __shfl_xor(a, 8); a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
-            if (l16 == 0) { cs[gi * GROUP_ROWS + rr] = ok ? a : -INFINITY; ci[gi * GROUP_ROWS + rr] = ok ? row : -1; }
+            float a = a0 + a1;
+            a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+            if (l8 == 0) { gs[gidx * GROUP_ROWS + rr] = ok ? a : -INFINITY; gi_[gidx * GROUP_ROWS + rr] = ok ? row : -1; }
         }
     }
     __syncthreads();
-    for (int r = 0; r < k; ++r) {
-        const int bp = block_argbest<RS_NT>(cs, ci, K * GROUP_ROWS, tid, red_s, red_i, red_p);
-        if (tid == 0) {
-            out_s[(int64_t)q * k + r] = bp >= 0 ? cs[bp] : -INFINITY;
-            out_i[(int64_t)q * k + r] = bp >= 0 ? ci[bp] + idx_base : -1;
-            if (bp >= 0) ci[bp] = -1;
+    // each wave: top-k of the rows of its groups (read back one row per lane)
+    {
+        float s[GPW]; int64_t id[GPW];
+#pragma unroll
+        for (int gq = 0; gq < GPW; ++gq) {
+            const int gidx = w + gq * RS_NW;
+            s[gq] = gidx < K ? gs[gidx * GROUP_ROWS + lane] : -INFINITY;
+            id[gq] = gidx < K ? gi_[gidx * GROUP_ROWS + lane] : -1;
         }
-        __syncthreads();
+        wave_topk<GPW>(s, id, k, lane, w_s[w], w_i[w]);
+    }
+    __syncthreads();
+    // (4) 16*k -> k
+    if (w == 0) {
+        constexpr int R4 = (RS_NW * KMAX + 63) / 64;
+        float s[R4]; int64_t id[R4];
+#pragma unroll
+        for (int j = 0; j < R4; ++j) {
+            const int i = j * 64 + lane;
+            s[j] = i < RS_NW * k ? w_s[i / k][i % k] : -INFINITY;
+            id[j] = i < RS_NW * k ? w_i[i / k][i % k] : -1;
+        }
+        wave_topk<R4>(s, id, k, lane, gs, gi_);
+        if (lane < k) {
+            out_s[(int64_t)q * k + lane] = gs[lane];
+            out_i[(int64_t)q * k + lane] = gi_[lane] >= 0 ? gi_[lane] + idx_base : -1;
+        }
     }
 }
 
@@ -364,9 +424,7 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
         ARX_HIP_CHECK(hipGetLastError());
     }
     const int nslices = L.nsplit;
-    const int ncand = nslices * K;
-    const int nmax = ncand > K * GROUP_ROWS ? ncand : K * GROUP_ROWS;
-    const size_t smem = (((size_t)nmax * 4 + 15) & ~(size_t)15) + (size_t)nmax * 8 + (size_t)D * 2;
+    const size_t smem = (((size_t)D * 2 + 15) & ~(size_t)15) + (size_t)K * GROUP_ROWS * 12;
     auto kern = rescore_kernel<K>;
     static size_t attr_max = 0;
     if (smem > 48 * 1024 && smem > attr_max) {
