@@ -151,7 +151,7 @@ def main():
             traffic = json.loads(tj.read_text()).get("gemm_fc1_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"kernel": "gemm_bf16_kernel<256,256,2,4,*,EPI_BIAS_GELU> (FFN-1: [T,768]x[3072,768]^T)", "bound": "mfma",
+    roofline = {"kernel": "gemm_v0e2_kernel<256,256,2,4,EPI_LN_BIAS_GELU,67> (FFN-1: LN1 folded, [T,768]x[3072,768]^T + erf-GELU)", "bound": "mfma",
                 "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_BF16, 4), "traffic": traffic,
                 "flops_per_launch": gemm_flops[dom]}
@@ -189,7 +189,18 @@ def main():
                                "passA_hbm_frac": round(passes_bytes / (gms / gn * 1e-3) / HBM_PEAK, 4),
                                "passA_tflops": round(2 * min(qb, 1024) * N * D / (gms / gn * 1e-3) / 1e12, 1),
                                "select_ms": round(p["search_select"][0] / reps, 3), "rescore_ms": round(p["search_rescore"][0] / reps, 3)}
-        search = {"workload": f"{N} x {D} fp16 rows per rank, {nq_all} queries, k=10, world {world}", "results": res}
+        r64 = res.get("Qb=64") or next(iter(res.values()))
+        straffic = None
+        if tj.exists():
+            try:
+                straffic = json.loads(tj.read_text()).get("search_groupmax64_hbm_bytes_per_launch")
+            except Exception:
+                straffic = None
+        search = {"workload": f"{N} x {D} fp16 rows per rank, {nq_all} queries, k=10, world {world}", "results": res,
+                  "roofline": {"kernel": "search_groupmax_kernel<64> (pass A at Qb=64)", "bound": "hbm",
+                               "achieved": r64["passA_hbm_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                               "frac": r64["passA_hbm_frac"], "traffic": straffic if N == 10_000_000 and D == 768 else None,
+                               "bytes_per_launch": N * D * 2}}
         del corpus, idx
         torch.cuda.empty_cache()
 
