@@ -373,6 +373,22 @@ static int launch_attn(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) 
     return big ? launch_attn_cfg<32, false, 8>(h, n_seqs, max_len, st) : launch_attn_cfg<32, false, 4>(h, n_seqs, max_len, st);
 }
 
+// Attention block alone (parity tap for the fused kernel): ctx[T,H] = softmax(q k^T / sqrt(dh) + bias, key mask) v
+// on caller-provided packed qkv [T, 3H] bf16; lens device int32 [n_seqs].
+extern "C" int32_t arx_encoder_attention(arx_encoder* h, const void* qkv, const int32_t* lens, int32_t n_seqs, int32_t max_len,
+                                         void* ctx, void* stream) {
+    ARX_REQUIRE(h && qkv && lens && ctx, "null pointer argument");
+    ARX_REQUIRE(n_seqs > 0 && n_seqs <= h->max_seqs && max_len > 0 && max_len <= 512, "bad n_seqs/max_len");
+    hipStream_t st = (hipStream_t)stream;
+    scan_lens_kernel<<<1, 256, 0, st>>>(lens, h->cu, n_seqs);
+    ARX_HIP_CHECK(hipGetLastError());
+    uint16_t* q0 = h->qkv; uint16_t* c0 = h->ctx;
+    h->qkv = (uint16_t*)qkv; h->ctx = (uint16_t*)ctx;
+    const int rc = launch_attn(h, n_seqs, max_len, st);
+    h->qkv = q0; h->ctx = c0;
+    return rc;
+}
+
 // ---- forward ------------------------------------------------------------------------------------
 extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32_t seq_stride, const int32_t* lens,
                                        int32_t n_seqs, int32_t max_len, int32_t total_tokens, float* out_f32,

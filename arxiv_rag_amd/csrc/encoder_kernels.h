@@ -388,22 +388,22 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     float* Bs = reinterpret_cast<float*>(smem + 2 * AttnSmem3<DH>::kv_bytes(Lk));
     const int bst = AttnSmem3<DH>::bias_stride(Lk);
 
-    {   // stage K (chunk ^ row swizzle) and V (chunk ^ 4*((row>>1)&1) for DH=64): this thread always owns physical
-        // chunk pc of rows r0, r0+RPI, ...; RPI is a multiple of 16, so both swizzle terms are per-thread constants
+    {   // stage K (chunk ^ row swizzle) and V (chunk ^ 4*((row>>1)&1) for DH=64) with direct global->LDS loads: every
+        // request of the block is in flight at once (one memory round trip instead of one per pass), no staging
+        // registers.  This thread always owns physical chunk pc of rows r0, r0+RPI, ... (RPI % 16 == 0 keeps both
+        // swizzle terms per-thread constants); the LDS image is lane-linear, the swizzle sits on the source address.
+        // Rows >= L re-read row L-1: finite values that the key mask / zero probabilities neutralise.
         static_assert(RPI % 16 == 0, "staging pass must keep the swizzle terms constant per thread");
+        typedef __attribute__((address_space(3))) void lds_v;
+        typedef const __attribute__((address_space(1))) void gbl_v;
         const int pc = tid % CPR, r0 = tid / CPR;
         const int kc = pc ^ ((r0 / RPB) & (CPR - 1));
         const int vc = (DH == 64) ? (pc ^ (((r0 >> 1) & 1) << 2)) : pc;
-        uint32_t gk = (uint32_t)r0 * ld + kc * 8, gv = (uint32_t)r0 * ld + vc * 8;
-        uint32_t lo = (uint32_t)tid * 16;
-        for (int row = r0; row < Lk; row += RPI, gk += RPI * ld, gv += RPI * ld, lo += NT * 16) {
-            u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
-            if (row < L) {
-                kv = *reinterpret_cast<const u32x4*>(Kg + gk);
-                vv = *reinterpret_cast<const u32x4*>(Vg + gv);
-            }
-            *reinterpret_cast<u32x4*>(Ks + lo) = kv;
-            *reinterpret_cast<u32x4*>(Vs + lo) = vv;
+        uint32_t lo = (uint32_t)(tid & ~63) * 16;
+        for (int row = r0; row < Lk; row += RPI, lo += NT * 16) {
+            const uint32_t gr = (uint32_t)(row < L ? row : L - 1) * ld;
+            __builtin_amdgcn_global_load_lds((gbl_v*)(Kg + gr + kc * 8), (lds_v*)(Ks + lo), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_v*)(Vg + gr + vc * 8), (lds_v*)(Vs + lo), 16, 0, 0);
         }
     }
     if (HAS_BIAS) {
@@ -451,17 +451,31 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-    auto tile = [&](auto masked_tag, int kt) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        f32x16 s;
+    // Online softmax with a LAZY reference: the running reference m_run is folded into the S accumulator's initial value
+    // (s0 = -m_run / scale), so fma(acc, scale, bias) already yields v - m_run and exp2 needs no subtraction; the
+    // reference is only moved (and O, l rescaled) when some lane's tile maximum exceeds it by more than THR (base-2
+    // units; P then stays <= 2^THR, exact up to the final normalisation).  Tile 0 always takes the exact-maximum path
+    // (no reference exists yet).  Row sums ride on the idle matrix pipe: l^T += ones . P^T (2 MFMAs per tile).
+    constexpr float THR = 8.0f;
+    const float inv_scale = 1.0f / scale_log2e;
+    f32x16 lacc;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    auto tile = [&](auto masked_tag, auto first_tag, int kt) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        f32x16 s;
+        const float s0 = FIRST ? 0.f : -m_run * inv_scale;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = s0;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kptr[ks]);
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
         }
-        float mx = -INFINITY;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -473,31 +487,34 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
                 s[g4 * 4 + e] = v;
             }
         }
+        float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        if (__any(m_new > m_run)) {
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
+        mx = fmaxf(mx, __shfl_xor(mx, 32));                   // tile maximum relative to the reference (FIRST: absolute)
+        if (FIRST) {
+            m_run = mx;                                       // finite: key 0 is always valid
 #pragma unroll
-            for (int d = 0; d < DB; ++d)
+            for (int r = 0; r < 16; ++r) s[r] -= mx;
+        } else if (__any(mx > THR)) {
+            const float d = fmaxf(mx, 0.f);                   // lanes whose maximum did not grow keep their reference
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            m_run += d;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            m_run = m_new;
+            for (int r = 0; r < 16; ++r) { s[r] -= d; lacc[r] *= alpha; }
+#pragma unroll
+            for (int dd = 0; dd < DB; ++dd)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
         }
-        float rs0 = 0.f, rs1 = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            s[r] = __builtin_amdgcn_exp2f(s[r] - m_run); s[r + 1] = __builtin_amdgcn_exp2f(s[r + 1] - m_run);
-            rs0 += s[r]; rs1 += s[r + 1];
-        }
-        l_run += rs0 + rs1;
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
         bf16x8 pf[2];
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss)
 #pragma unroll
             for (int e = 0; e < 8; ++e) pf[ss][e] = (bf16_t)s[8 * ss + e];
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[ss], lacc, 0, 0, 0);
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
 #pragma unroll
@@ -519,10 +536,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     };
     const int nkt = Lk >> 5;
     const int nfull = (L & 31) ? nkt - 1 : nkt;           // tiles with no masked key
-    for (int kt = 0; kt < nfull; ++kt) tile(std::false_type{}, kt);
-    if (nfull < nkt) tile(std::true_type{}, nkt - 1);
+    if (nfull > 0) tile(std::false_type{}, std::true_type{}, 0); else tile(std::true_type{}, std::true_type{}, 0);
+    for (int kt = 1; kt < nfull; ++kt) tile(std::false_type{}, std::false_type{}, kt);
+    if (nfull < nkt && nkt > 1) tile(std::true_type{}, std::false_type{}, nkt - 1);
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = lacc[0];                           // every accumulator row holds the same sum over all keys
+    (void)l_run;
     const float inv = 1.0f / l_tot;
     if (q < L) {
         uint16_t* orow = ctx + (int64_t)(t0 + q) * H + h * DH;

@@ -113,6 +113,11 @@ int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32_t seq_stri
                             void* out_f16, int64_t out16_stride,
                             int32_t normalize, void* stream);
 
+/* The fused attention block alone, on caller-provided packed qkv [sum(lens), 3H] bf16 -> ctx [sum(lens), H] bf16
+ * (parity tap: lets a test drive the online-softmax rescale path with crafted scores). */
+int32_t arx_encoder_attention(arx_encoder* h, const void* qkv, const int32_t* lens, int32_t n_seqs, int32_t max_len,
+                              void* ctx, void* stream);
+
 /* Debug / parity tap: copy the packed hidden state after `layer` (0 = embeddings, L = last) as f32
  * [total_tokens, H] into dst (device).  Valid after a forward on the same stream. */
 int32_t arx_encoder_debug_hidden(arx_encoder* h, int32_t layer_slot, float* dst, int32_t n_tokens, void* stream);

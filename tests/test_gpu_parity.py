@@ -310,3 +310,58 @@ def test_search_distributed_single_rank_nccl(hip):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("preset", ["all-mpnet-base-v2", "all-MiniLM-L6-v2"])
+def test_attention_block_forced_rescale(hip, preset):
+    """The fused attention kernel alone on crafted q/k/v: (a) ordinary scores, (b) a late key whose score jumps far
+    above everything before it (forces the lazy-reference rescale branch, cdna guide rule 26), (c) a first tile of very
+    negative scores followed by large ones, (d) ragged lengths incl. 1 and a 33-token row (masked last tile).
+    Reference: fp64 softmax attention on the same bf16-rounded inputs, MPNet bias from the oracle's Toeplitz table."""
+    from arxiv_rag_amd.encoder import HipEncoder
+    cfg = C.PRESETS[preset]
+    sd = seeded_state_dict(cfg, seed=9, std=0.02)
+    enc = HipEncoder(cfg, sd, max_tokens=4096, max_seqs=16)
+    H, nh = cfg.hidden, cfg.heads
+    dh = H // nh
+    lens = np.array([256, 200, 33, 1, 64, 255, 97], np.int32)
+    T = int(lens.sum())
+    rs = np.random.RandomState(4)
+    qkv = rs.standard_normal((T, 3 * H)).astype(np.float32)
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    # (b) sequence 0: key 230 aligned with every query of head 0, 40x larger -> score jump >> 8 (log2 units) at tile 7
+    qkv[cu[0] + 230, H:H + dh] = 40.0 * np.sign(qkv[cu[0]:cu[1], 0:dh].mean(0) + 1e-3)
+    qkv[cu[0]:cu[1], 0:dh] = np.abs(qkv[cu[0]:cu[1], 0:dh]) * np.sign(qkv[cu[0] + 230, H:H + dh])
+    # (c) sequence 1, head 1: first 32 keys anti-aligned (very negative scores), later keys strongly aligned
+    qh = slice(dh, 2 * dh)
+    base = np.sign(rs.standard_normal(dh)).astype(np.float32)
+    qkv[cu[1]:cu[2], qh] = base * (1 + 0.1 * rs.rand(200, dh))
+    qkv[cu[1]:cu[1] + 32, H + dh:H + 2 * dh] = -30.0 * base
+    qkv[cu[1] + 32:cu[2], H + dh:H + 2 * dh] = 6.0 * base * rs.rand(168, 1)
+    q16 = torch.from_numpy(qkv).to(torch.bfloat16)
+    qd = q16.cuda().contiguous()
+    ctx = torch.full((T, H), float("nan"), dtype=torch.bfloat16, device="cuda")
+    rc = hip.load().arx_encoder_attention(enc._handle, qd.data_ptr(), torch.from_numpy(lens).cuda().data_ptr(), len(lens), 256,
+                                          ctx.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    hip.check(rc, "arx_encoder_attention")
+    got = ctx.float().cpu().numpy()
+    x = q16.float().numpy().astype(np.float64)
+    tbl = EO.toeplitz_bias_table(sd, cfg, 256)              # [heads, 511] or None
+    worst = 0.0
+    for b in range(len(lens)):
+        L = lens[b]
+        seg = x[cu[b]:cu[b + 1]]
+        for hd in range(nh):
+            q = seg[:, hd * dh:(hd + 1) * dh]; k = seg[:, H + hd * dh:H + (hd + 1) * dh]; v = seg[:, 2 * H + hd * dh:2 * H + (hd + 1) * dh]
+            sc = q @ k.T / np.sqrt(dh)
+            if tbl is not None:
+                i, j = np.meshgrid(np.arange(L), np.arange(L), indexing="ij")
+                sc = sc + tbl[hd][j - i + 255]
+            sc -= sc.max(1, keepdims=True)
+            p = np.exp(sc); p /= p.sum(1, keepdims=True)
+            ref = p @ v
+            err = np.abs(got[cu[b]:cu[b + 1], hd * dh:(hd + 1) * dh] - ref).max() / (np.abs(v).max() + 1e-9)
+            worst = max(worst, err)
+    assert np.isfinite(got).all()
+    assert worst < 2e-2, worst                  # bf16 P and bf16 output; relative to max |v| of the head
+    enc.close()
