@@ -365,3 +365,22 @@ def test_attention_block_forced_rescale(hip, preset):
     assert np.isfinite(got).all()
     assert worst < 2e-2, worst                  # bf16 P and bf16 output; relative to max |v| of the head
     enc.close()
+
+
+def test_collection_query_shape_and_ranking(hip, tmp_path):
+    """stage-4 files -> HBM-resident collection -> Chroma-shaped query."""
+    from arxiv_rag_amd import generate_embeddings_parallel as GEN
+    from arxiv_rag_amd.store import HipCollection
+    Cm = SO.unit_rows_f16(3000, 128, 5).astype(np.float32)
+    chunks = [{"chunk_id": f"c{i}", "text": f"text {i}", "metadata": {"paper_id": f"p{i % 7}", "section": "s", "quality_score": 0.9}} for i in range(3000)]
+    GEN.save_embeddings_to_disk_fallback(chunks, list(Cm), output_dir=str(tmp_path / "saved"))
+    col = HipCollection.from_disk(tmp_path / "saved")
+    assert col.count() == 3000
+    Q = SO.unit_rows_f16(4, 128, 6)
+    res = col.query(query_embeddings=Q.astype(np.float32), n_results=10)
+    rs, ri = SO.topk_search(Cm.astype(np.float16), Q, 10)
+    for qi in range(4):
+        assert res["indices"][qi] == ri[qi].tolist()
+        assert res["ids"][qi] == [f"c{j}" for j in ri[qi]]
+        assert np.allclose(res["distances"][qi], 2 - 2 * rs[qi], atol=1e-5)
+        assert res["documents"][qi][0] == f"text {ri[qi][0]}" and res["metadatas"][qi][0]["paper_id"] == f"p{ri[qi][0] % 7}"

@@ -273,3 +273,28 @@ def test_world_size_2_gloo_matches_single_process(tmp_path, tiny_model):
         os.chdir(cwd)
     for n in ("embeddings.npy", "metadata.json", "index.json"):
         assert (tmp_path / "out1" / "embeddings_saved" / n).read_bytes() == (tmp_path / "out2" / "embeddings_saved" / n).read_bytes(), n
+
+
+# ------------------------------------------------------------------ on-disk layouts -> loader
+def test_load_embeddings_from_disk_both_layouts(tmp_path):
+    """GEN layout (written by our writer, byte-checked above) and the batched layout of
+    4-embed/utils/save_embeddings_to_disk.py:15-80 (files produced here by hand in that format)."""
+    from arxiv_rag_amd.store import load_embeddings_from_disk
+    rs = np.random.RandomState(0)
+    chunks = [{"chunk_id": f"c{i}", "text": f"t{i}", "metadata": {"paper_id": "p", "section": "s", "quality_score": 0.95}} for i in range(25)]
+    embs = rs.standard_normal((25, 8)).astype(np.float32)
+    GEN.save_embeddings_to_disk_fallback(chunks, list(embs), output_dir=str(tmp_path / "gen"))
+    e, m = load_embeddings_from_disk(tmp_path / "gen")
+    assert e.shape == (25, 8) and e.dtype == np.float64 and np.allclose(e, embs) and [x["chunk_id"] for x in m] == [c["chunk_id"] for c in chunks]
+    b = tmp_path / "batched"; b.mkdir()
+    for i in range(3):
+        lo, hi = i * 10, min(25, i * 10 + 10)
+        np.save(b / f"embeddings_batch_{i:04d}.npy", embs[lo:hi].astype(np.float64))
+        (b / f"metadata_batch_{i:04d}.json").write_text(json.dumps(
+            [{"chunk_id": f"c{j}", "text": f"t{j}", "batch_index": i, "batch_position": j - lo} for j in range(lo, hi)]))
+    (b / "index.json").write_text(json.dumps({"total_embeddings": 25, "embedding_dimension": 8, "num_batches": 3, "batch_size": 10,
+                                              "chunks": [f"c{j}" for j in range(25)]}))
+    e2, m2 = load_embeddings_from_disk(b)
+    assert np.allclose(e2, embs) and [x["chunk_id"] for x in m2] == [f"c{j}" for j in range(25)]
+    e3, m3 = load_embeddings_from_disk(b, batch_index=2)
+    assert e3.shape == (5, 8) and m3[0]["chunk_id"] == "c20"
