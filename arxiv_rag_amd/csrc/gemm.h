@@ -519,3 +519,78 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_v0e2_kernel(const bf16_t* _
 //  once chip-wide, no pre-LN tensor in HBM — was built and measured: its 48 KB-per-half-step W stream left only
 //  2 x BK=32 LDS stages and it ran 674 TF on FFN-2 / 398 TF on the O projection, slower than the 256^2 kernel
 //  plus the separate LayerNorm kernel (1.40 / 0.65 ms vs 1.84 / 0.78 ms); removed.  DESIGN.md §4.)
+
+// =====================================================================================================
+// "A3W2" main loop: same 256x256x64 tile, LDS images and MFMA order as the default kernel, but the streamed A
+// operand (activations, HBM/MALL latency) rides a THREE-slot ring kept two k-steps ahead while the small, L2-resident
+// W operand stays double-buffered: 3*32 KB + 2*32 KB = 160 KB = the whole LDS of a CU.  The prefetch distance is
+// expressed by a counted s_waitcnt (the A tile issued last stays in flight across the raw s_barrier).
+template <int BM, int BN, int WM, int WN, int MODE, int KROT = 2>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_a3w2_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                  const bf16_t* __restrict__ W, int64_t ldw,
+                                                                  int M, int N, int K, int tiles_m, int tiles_n,
+                                                                  EpiParams ep) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 16, NI = TN / 16;
+    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128;
+    constexpr int LA = BM * 8 / NT, LW = BN * 8 / NT;          // global_load_lds per wave per tile
+    using vec = typename Mfma<bf16_t>::vec;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Abuf = smem;                                   // 3 slots
+    char* const Wbuf = smem + 3 * A_BYTES;                     // 2 slots
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tile_m = t / tiles_n, tile_n = t % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const uint16_t* Ag = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* Wg = reinterpret_cast<const uint16_t*>(W);
+    const int nk = K >> 6;
+    const int koff = (tile_n * KROT) % nk;
+    auto kcol = [&](int kt) { int k = kt + koff; return (k >= nk ? k - nk : k) << 6; };
+    u32x4 dummy_a[LA], dummy_w[LW];
+    auto issueA = [&](int kt) { stage_issue<BM, NT, true, 0>(Ag, lda, m0, M - 1, kcol(kt), Abuf + (kt % 3) * A_BYTES, tid, dummy_a); };
+    auto issueW = [&](int kt) { stage_issue<BN, NT, true, 0>(Wg, ldw, n0, N - 1, kcol(kt), Wbuf + (kt & 1) * W_BYTES, tid, dummy_w); };
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4, sw = (lane >> 1) & 7;
+    const int off0 = frow * 128 + (((0 + fq) ^ sw) << 4);
+    const int off1 = frow * 128 + (((4 + fq) ^ sw) << 4);
+    const int a_base = wm * TM * 128, w_base = wn * TN * 128;
+
+    // prologue: A(0), W(0), A(1) in flight; A(0) and W(0) must land, A(1) may stay in flight
+    issueA(0); issueW(0);
+    if (nk > 1) { issueA(1); wait_vmcnt<LA>(); } else { wait_vmcnt<0>(); }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // queue on entry (oldest first): [A(kt+1)]           -> issue W(kt+1), A(kt+2)
+        if (kt + 1 < nk) issueW(kt + 1);
+        if (kt + 2 < nk) issueA(kt + 2);
+        const char* As = Abuf + (kt % 3) * A_BYTES + a_base;
+        const char* Ws = Wbuf + (kt & 1) * W_BYTES + w_base;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int off = ks ? off1 : off0;
+            vec af[MI], wf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec*>(As + i * 2048 + off);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const vec*>(Ws + j * 2048 + off);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<bf16_t>::mma(wf[j], af[i], acc[j][i]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // A(kt+1) and W(kt+1) must have landed; only A(kt+2) (the youngest LA loads) may remain in flight
+        if (kt + 2 < nk) wait_vmcnt<LA>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    epilogue_store_v2<MODE, NI, MI>(acc, ep, m0 + wm * TM, n0 + wn * TN, lane, M, N);
+}

@@ -384,3 +384,28 @@ def test_collection_query_shape_and_ranking(hip, tmp_path):
         assert res["ids"][qi] == [f"c{j}" for j in ri[qi]]
         assert np.allclose(res["distances"][qi], 2 - 2 * rs[qi], atol=1e-5)
         assert res["documents"][qi][0] == f"text {ri[qi][0]}" and res["metadatas"][qi][0]["paper_id"] == f"p{ri[qi][0] % 7}"
+
+
+@pytest.mark.parametrize("variant", [13, 33, 15, 1, 3, 2, 0, 4])
+def test_linear_layer_variants_vs_fp32(hip, variant):
+    """arx_gemm_bf16 (the linear layer of the path) against an fp32 matmul on the same bf16-rounded operands:
+    every main-loop schedule kept in the tree, every epilogue mode it supports, ragged M/N (masked edge tiles)."""
+    lib = hip.load()
+    g = torch.Generator(device="cuda"); g.manual_seed(variant)
+    st = torch.cuda.current_stream().cuda_stream
+    for (M, N, K) in ((230, 192, 64), (517, 64, 128), (1000, 384, 384), (300, 1536, 384), (777, 768, 768), (2048, 2304, 768)):
+        A = torch.randn((M, K), device="cuda", generator=g).to(torch.bfloat16)
+        W = (torch.randn((N, K), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn((N,), device="cuda", generator=g)
+        R = torch.randn((M, N), device="cuda", generator=g).to(torch.bfloat16)
+        for mode in (0, 1, 2):
+            want = A.float() @ W.float().T + b
+            if mode == 1:
+                want = torch.nn.functional.gelu(want)
+            if mode == 2:
+                want = want + R.float()
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            hip.check(lib.arx_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, mode,
+                                        variant, st), "arx_gemm_bf16")
+            err = (out.float() - want).abs().max().item()
+            assert err < 0.02 * max(1.0, want.abs().max().item()), (variant, M, N, K, mode, err)
