@@ -266,6 +266,10 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
             return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, false, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, false>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a7);
         }
     }
+    if (variant == 34 && wide) {      // ping-pong: the two waves of a SIMD half a k-step apart
+        static bool r2 = false;
+        return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 64 + 4096>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 64 + 4096>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &r2);
+    }
     if (variant == 33 && wide) {      // A operand 3-deep (two k-steps ahead), W double-buffered, 160 KB LDS
         static bool r0 = false;
         return launch_gemm_kernel(gemm_a3w2_kernel<256, 256, 2, 4, MODE>, 3 * 256 * 128 + 2 * 256 * 128, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &r0);

@@ -104,6 +104,41 @@ struct GemmMainloop {
             stage_commit<BN, NT>(smem + A_BYTES, tid, rw);
         }
         __syncthreads();
+        if constexpr ((OPT & 4096) && GLDS) {
+            // REGISTER-DOUBLE-BUFFERED FRAGMENTS: every MFMA cluster runs while the ds_reads of the NEXT cluster are in
+            // flight (two fragment sets); the second cluster of step kt executes at the start of step kt+1, after the
+            // barrier, from fragments read before it.  Uniform control flow for all waves.
+            vec af0[MI], wf0[NI], af1[MI], wf1[NI];
+            auto rd = [&](const char* stage, int off, vec (&af)[MI], vec (&wf)[NI]) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec*>(stage + a_base + i * 2048 + off);
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const vec*>(stage + A_BYTES + w_base + j * 2048 + off);
+            };
+            auto mm = [&](const vec (&af)[MI], const vec (&wf)[NI]) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<T>::mma(wf[j], af[i], acc[j][i]);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            for (int kt = 0; kt < nk; ++kt) {
+                const char* cur = smem + (kt & 1) * STAGE_BYTES;
+                char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
+                if (kt + 1 < nk) {
+                    stage_issue<BM, NT, GLDS, OPT>(Ag, lda, m0, M - 1, kstep(kt + 1), nxt, tid, ra);
+                    stage_issue<BN, NT, GLDS, (OPT & ~16)>(Wg, ldw, n0, N - 1, kstep(kt + 1), nxt + A_BYTES, tid, rw);
+                }
+                rd(cur, off0, af0, wf0);                 // first cluster's fragments of this step
+                if (kt > 0) mm(af1, wf1);                // second cluster of the previous step
+                rd(cur, off1, af1, wf1);                 // second cluster's fragments (consumed after the barrier)
+                mm(af0, wf0);
+                __syncthreads();
+            }
+            mm(af1, wf1);
+            return;
+        }
         for (int kt = 0; kt < nk; ++kt) {
             char* cur = smem + (kt & 1) * STAGE_BYTES;
             char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;

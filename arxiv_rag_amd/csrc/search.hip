@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
                                                                const f16_t* __restrict__ C, int64_t n_rows, int D,
                                                                int tiles_q, int tiles_n, float* __restrict__ gmax,
                                                                int64_t ldg) {
-    using ML = GemmMainloop<f16_t, BM, 256, 2, 4, GLDS>;
+    using ML = GemmMainloop<f16_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;      // stagger + setprio as in the encoder GEMM
     static_assert(ML::TN == GROUP_ROWS, "one wave column = one group");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = xcd_remap(blockIdx.x, tiles_q * tiles_n);
@@ -40,7 +40,8 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
     f32x4 acc[ML::NI][ML::MI];
     // rows are addressed relative to the tile so 32-bit row math stays in range for any shard size
     const int rows_here = (int)((n_rows - n0) < 256 ? (n_rows - n0) : 256);
-    ML::run(Q, D, nq, C + n0 * D, D, rows_here, D, m0, 0, smem, acc);
+    // k rotation by query tile: the tiles_q blocks that share this corpus tile do not miss on the same lines at once
+    ML::run(Q, D, nq, C + n0 * D, D, rows_here, D, m0, 0, smem, acc, tile_q * 2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm = wid / 4, wn = wid % 4;
     if (wn * GROUP_ROWS >= rows_here) return;
@@ -389,7 +390,7 @@ extern "C" int64_t arx_topk_workspace_bytes(int64_t n_rows, int32_t n_queries, i
 
 template <int BM, bool GLDS>
 static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D, float* gmax, int64_t ldg, hipStream_t st) {
-    using ML = GemmMainloop<f16_t, BM, 256, 2, 4, GLDS>;
+    using ML = GemmMainloop<f16_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
     auto kern = search_groupmax_kernel<BM, GLDS>;
     static bool attr_set = false;
     if (!attr_set) {
