@@ -55,9 +55,28 @@ def cpu_baseline(cfg, sd, S, budget_s=20.0):
         cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
     except Exception:
         cores = os.cpu_count() or 1
-    return {"value": round(n / t, 3), "unit": "chunks/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n} chunks x {S} tokens, {cfg.layers}L/{cfg.hidden} fp32 numpy oracle (oracle/encoder_oracle.py), "
-                      f"batch {B}, host has {os.cpu_count()} logical cpus"}
+    out = {"value": round(n / t, 3), "unit": "chunks/s", "cores": int(cores), "kind": "port",
+           "sample": f"{n} chunks x {S} tokens, {cfg.layers}L/{cfg.hidden} fp32 numpy oracle (oracle/encoder_oracle.py), "
+                     f"batch {B}, host has {os.cpu_count()} logical cpus"}
+    # reference-equivalent CPU (BASELINE.md §3 CPU-A): transformers MPNetModel fp32 eager + pool + L2, torch threads = cores
+    try:
+        import torch
+        from oracle import tf_reference as TF
+        tn = torch.get_num_threads()
+        m = TF.build_model(cfg, sd)
+        B2 = 32
+        ids2 = rs.randint(4, cfg.vocab_size - 1, size=(B2, S)).astype(np.int64); ids2[:, 0] = 0; ids2[:, -1] = 2
+        lens2 = np.full(B2, S, np.int64)
+        TF.encode_tokens(m, cfg, ids2[:4], lens2[:4])
+        n2, t2 = 0, 0.0
+        while t2 < min(10.0, budget_s * 0.5) or n2 == 0:
+            t0 = time.time(); TF.encode_tokens(m, cfg, ids2, lens2); t2 += time.time() - t0; n2 += B2
+        out["reference_equivalent"] = {"value": round(n2 / t2, 2), "unit": "chunks/s", "threads": int(tn),
+                                       "what": f"transformers {cfg.layers}L/{cfg.hidden} fp32 eager + pool + L2 (oracle/tf_reference.py), "
+                                               f"{n2} chunks x {S} tokens, batch {B2}"}
+    except Exception as e:                                   # noqa: BLE001
+        out["reference_equivalent"] = {"error": repr(e)[:200]}
+    return out
 
 
 def main():

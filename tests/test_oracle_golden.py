@@ -127,3 +127,19 @@ def test_search_k_larger_than_n():
     Cm = SO.unit_rows_f16(4, 32, 1); Q = SO.unit_rows_f16(2, 32, 2)
     s, i = SO.topk_search(Cm, Q, 10)
     assert (i[:, 4:] == -1).all() and np.isneginf(s[:, 4:]).all() and (i[:, :4] >= 0).all()
+
+
+def test_oracle_vs_transformers_direct():
+    """The numpy restatement against the third-party modules themselves (oracle/tf_reference.py), fresh inputs."""
+    pytest.importorskip("transformers")
+    from oracle import tf_reference as TF
+    for cfg in (C.TINY_MPNET, C.TINY_BERT_CLS):
+        sd = seeded_state_dict(cfg, seed=21, std=0.06, bias_std=0.03, ln_jitter=0.1)
+        rs = np.random.RandomState(2)
+        lens = np.array([40, 7, 1, 64, 33], np.int64)
+        ids = np.full((5, 64), cfg.pad_id, np.int64)
+        for r, n in enumerate(lens):
+            ids[r, :n] = rs.randint(4, cfg.vocab_size, size=n)
+        ref = TF.encode_tokens(TF.build_model(cfg, sd), cfg, ids, lens)
+        got = EO.encode_tokens(sd, cfg, ids, lens)
+        assert np.abs(got - ref).max() < 5e-6

@@ -36,26 +36,8 @@ GEN = Path("/root/reference/4-embed/generation/generate_embeddings_parallel.py")
 
 
 def build_tf_model(cfg: C.EncoderConfig, sd):
-    import transformers
-    if cfg.arch == C.ARCH_MPNET:
-        hc = transformers.MPNetConfig(
-            vocab_size=cfg.vocab_size, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
-            num_attention_heads=cfg.heads, intermediate_size=cfg.ffn,
-            max_position_embeddings=cfg.max_pos, layer_norm_eps=cfg.ln_eps,
-            relative_attention_num_buckets=cfg.rel_buckets, hidden_dropout_prob=0.0,
-            attention_probs_dropout_prob=0.0)
-        m = transformers.MPNetModel(hc, add_pooling_layer=False)
-    else:
-        hc = transformers.BertConfig(
-            vocab_size=cfg.vocab_size, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
-            num_attention_heads=cfg.heads, intermediate_size=cfg.ffn,
-            max_position_embeddings=cfg.max_pos, layer_norm_eps=cfg.ln_eps,
-            hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager")
-        m = transformers.BertModel(hc, add_pooling_layer=False)
-    res = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
-    assert not res.unexpected_keys, res.unexpected_keys
-    assert all("position_ids" in k or "token_type_ids" in k for k in res.missing_keys), res.missing_keys
-    return m.eval()
+    from oracle import tf_reference as TF
+    return TF.build_model(cfg, sd)
 
 
 def tf_encode(m, cfg, ids, lens, all_hidden=False):
