@@ -8,8 +8,8 @@ never-raise-per-chunk policy (GEN:155-177).  What changes is underneath: one pro
 encoder and keeps its rows in HBM as its fp16 corpus shard; an optional `--queries` step then serves
 brute-force cosine top-k over the shards (RCCL all-gather of partial top-k).
 
-Additive flags only: --model also takes a local directory; --model-dir, --device-index, --out-dtype,
---queries, --top-k, --skip-chroma, --max-seq-length.
+Additive flags only: --model also takes a local directory; --model-dir, --out-dtype, --queries, --top-k,
+--skip-chroma.
 """
 from __future__ import annotations
 
@@ -182,6 +182,61 @@ def generate_embeddings_parallel(chunks: List[Dict], model_name: str = "all-mpne
     return embeddings
 
 
+def generate_embeddings_sharded(chunks: List[Dict], model_name: str, batch_size: int = 200,
+                                chunks_per_worker: int = 500) -> Tuple[np.ndarray, int, int]:
+    """Multi-rank form of the dispatcher: this rank encodes a contiguous range of quanta and KEEPS its rows
+    (no exchange of embeddings: at ~5 M chunks x 768 that would be 15 GB per rank for nothing).
+    Returns (rows float32 [hi-lo, D], lo, hi) with row j <-> chunk lo + j; failed quanta are zero rows."""
+    texts = [c["text"] for c in chunks]
+    dist = _dist()
+    world = dist.get_world_size() if dist else 1
+    rank = dist.get_rank() if dist else 0
+    n_quanta = (len(texts) + chunks_per_worker - 1) // chunks_per_worker
+    q_lo, q_hi = shard_range(n_quanta, world, rank)
+    lo, hi = min(len(texts), q_lo * chunks_per_worker), min(len(texts), q_hi * chunks_per_worker)
+    print(f"[rank {rank}] encoding chunks [{lo:,}, {hi:,}) of {len(texts):,} ({q_hi - q_lo} quanta)")
+    dim = get_worker_model(model_name).get_sentence_embedding_dimension()
+    rows = np.zeros((hi - lo, dim), np.float32)
+    errors = 0
+    for qi in range(q_lo, q_hi):
+        a, b = qi * chunks_per_worker, min(len(texts), (qi + 1) * chunks_per_worker)
+        idx, got, err = generate_embeddings_worker((texts[a:b], model_name, batch_size, qi))
+        if err or len(got) != b - a:
+            errors += 1
+            print(f"Warning: Batch {idx} produced {len(got)} of {b - a} embeddings; missing rows stay zero")
+        for j, e in enumerate(got[:b - a]):
+            rows[a - lo + j] = e
+    if errors:
+        print(f"⚠️  [rank {rank}] {errors} batches had errors")
+    return rows, lo, hi
+
+
+def save_embeddings_sharded(chunks: List[Dict], rows: np.ndarray, lo: int, hi: int,
+                            output_dir: str = "./embeddings_saved", out_dtype: str = "float64"):
+    """Same three files as save_embeddings_to_disk_fallback, written cooperatively: rank 0 creates embeddings.npy
+    (header + size), every rank stores its own row range through a memmap, rank 0 writes metadata/index."""
+    dist = _dist()
+    rank = dist.get_rank() if dist else 0
+    out = Path(output_dir)
+    n, dim = len(chunks), rows.shape[1]
+    if rank == 0:
+        out.mkdir(parents=True, exist_ok=True)
+        arr = np.lib.format.open_memmap(out / "embeddings.npy", mode="w+", dtype=np.dtype(out_dtype), shape=(n, dim))
+        del arr
+    if dist:
+        dist.barrier()
+    arr = np.load(out / "embeddings.npy", mmap_mode="r+")
+    arr[lo:hi] = rows.astype(np.dtype(out_dtype))
+    nbytes = arr.nbytes
+    arr.flush()
+    del arr
+    if dist:
+        dist.barrier()
+    if rank == 0:
+        _write_metadata_and_index(chunks, out, n, dim, nbytes)
+        print(f"✅ Saved {n:,} embeddings ({dim} dimensions) from {dist.get_world_size() if dist else 1} rank(s)")
+
+
 # --------------------------------------------------------------------------------------------- write
 def save_embeddings_to_disk_fallback(chunks: List[Dict], embeddings: Sequence, output_dir: str = "./embeddings_saved",
                                      out_dtype: str = "float64"):
@@ -201,6 +256,12 @@ def save_embeddings_to_disk_fallback(chunks: List[Dict], embeddings: Sequence, o
     arr.flush()
     del arr
     print(f"✅ Saved embeddings to {out / 'embeddings.npy'}")
+    _write_metadata_and_index(chunks, out, n, dim, nbytes)
+    print(f"✅ Saved {n:,} embeddings ({dim} dimensions)")
+    print(f"   Total size: ~{nbytes / 1024 / 1024 / 1024:.2f} GB")
+
+
+def _write_metadata_and_index(chunks: List[Dict], out: Path, n: int, dim: int, nbytes: int):
     meta = []
     for i, ch in enumerate(chunks):
         m = ch.get("metadata", {})
@@ -213,8 +274,6 @@ def save_embeddings_to_disk_fallback(chunks: List[Dict], embeddings: Sequence, o
     index = {"total_embeddings": n, "embedding_dimension": dim, "total_size_gb": nbytes / 1024 / 1024 / 1024}
     with open(out / "index.json", "w", encoding="utf-8") as fh:
         json.dump(index, fh, indent=2)
-    print(f"✅ Saved {n:,} embeddings ({dim} dimensions)")
-    print(f"   Total size: ~{nbytes / 1024 / 1024 / 1024:.2f} GB")
 
 
 def store_in_chroma_batched(chunks: List[Dict], embeddings: Sequence, db_path: str = "./chroma_db",
@@ -263,7 +322,7 @@ def store_in_chroma_batched(chunks: List[Dict], embeddings: Sequence, db_path: s
 
 # --------------------------------------------------------------------------------------------- search (added step)
 def search_queries(model, chunks: List[Dict], embeddings: Sequence, queries: List[str], top_k: int = 10,
-                   output_dir: str = "./embeddings_saved") -> List[Dict]:
+                   output_dir: str = "./embeddings_saved", local_range: Optional[Tuple[int, int]] = None) -> List[Dict]:
     """Brute-force cosine top-k (config.yaml:63-64 `top_k: 10`) over the rank's fp16 rows in HBM; with
     torchrun each rank holds the contiguous row shard it encoded and the partial top-k lists are
     all-gathered over RCCL and merged."""
@@ -272,10 +331,14 @@ def search_queries(model, chunks: List[Dict], embeddings: Sequence, queries: Lis
     dist = _dist()
     world = dist.get_world_size() if dist else 1
     rank = dist.get_rank() if dist else 0
-    n = len(embeddings)
-    lo, hi = shard_bounds(n, world, rank)
     dev = model.encoder.device
-    shard = torch.from_numpy(np.asarray(embeddings[lo:hi], dtype=np.float16)).to(dev) if hi > lo else \
+    if local_range is not None:                       # `embeddings` already holds only this rank's rows [lo, hi)
+        lo, hi = local_range
+        local = embeddings
+    else:
+        lo, hi = shard_bounds(len(embeddings), world, rank)
+        local = embeddings[lo:hi]
+    shard = torch.from_numpy(np.asarray(local, dtype=np.float16)).to(dev) if hi > lo else \
         torch.empty((0, model.get_sentence_embedding_dimension()), dtype=torch.float16, device=dev)
     q = model.encode(queries, batch_size=256, normalize_embeddings=True, convert_to_numpy=True)
     qd = torch.from_numpy(np.asarray(q, dtype=np.float16)).to(dev)
@@ -367,18 +430,26 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
             print(f"Error: embedding backend not available: {e}")
             return 1
         t0 = time.time()
-        embeddings = generate_embeddings_parallel(chunks, model_name=args.model, batch_size=args.batch_size,
-                                                  num_workers=args.embedding_workers, chunks_per_worker=args.chunks_per_worker)
+        local_range = None
+        if world > 1:
+            # one process per GPU: every rank encodes, keeps and writes its own contiguous row range
+            embeddings, lo, hi = generate_embeddings_sharded(chunks, args.model, args.batch_size, args.chunks_per_worker)
+            local_range = (lo, hi)
+        else:
+            embeddings = generate_embeddings_parallel(chunks, model_name=args.model, batch_size=args.batch_size,
+                                                      num_workers=args.embedding_workers, chunks_per_worker=args.chunks_per_worker)
         embedding_time = time.time() - t0
         print(f"Embedding generation completed in {embedding_time:.1f} seconds ({embedding_time / 60:.1f} min)\n")
-        if rank == 0:
+        if world > 1:
+            save_embeddings_sharded(chunks, embeddings, lo, hi, output_dir="./embeddings_saved", out_dtype=args.out_dtype)
+        elif rank == 0:
             print("Saving embeddings to disk as backup...")
             save_embeddings_to_disk_fallback(chunks, embeddings, output_dir="./embeddings_saved", out_dtype=args.out_dtype)
             print()
         if args.queries:
             qs = [ln.strip() for ln in Path(args.queries).read_text(encoding="utf-8").splitlines() if ln.strip()]
             if qs:
-                search_queries(_model, chunks, embeddings, qs, top_k=args.top_k)
+                search_queries(_model, chunks, embeddings, qs, top_k=args.top_k, local_range=local_range)
         store_time = 0.0
         if rank == 0 and not args.skip_chroma:
             try:
@@ -388,6 +459,8 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
                 print("Install with: pip install chromadb")
                 return 1
             t0 = time.time()
+            if world > 1:                       # rank 0 only holds its shard: ingest from the file all ranks just wrote
+                embeddings = np.load(Path("./embeddings_saved") / "embeddings.npy", mmap_mode="r")
             try:
                 store_in_chroma_batched(chunks, embeddings, db_path=args.chroma_db, collection_name=args.collection_name,
                                         batch_size=args.store_batch_size)
@@ -402,7 +475,7 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
         print("EMBEDDING GENERATION COMPLETE")
         print("=" * 80)
         print(f"Chunks processed: {len(chunks):,}")
-        print(f"Embeddings generated: {len(embeddings):,}")
+        print(f"Embeddings generated: {len(chunks) if world > 1 else len(embeddings):,}")
         if len(embeddings):
             print(f"Embedding dimensions: {len(embeddings[0])}")
         print(f"Stored in: {args.chroma_db}\n")
