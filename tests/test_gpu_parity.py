@@ -349,3 +349,25 @@ def test_linear_layer_variants_vs_fp32(hip, variant):
                                         variant, st), "arx_gemm_bf16")
             err = (out.float() - want).abs().max().item()
             assert err < 0.02 * max(1.0, want.abs().max().item()), (variant, M, N, K, mode, err)
+
+
+@pytest.mark.parametrize("env", [{"ARX_LN_FOLD": "0"}, {"ARX_ATTN_VARIANT": "0"}, {"ARX_GEMM_VARIANT": "3"}])
+def test_alternative_schedules_agree(hip, golden_dir, env, monkeypatch):
+    """The A/B schedules kept in the tree (explicit LayerNorm kernels, first attention kernel, ring GEMM) against the same
+    golden vectors as the default path, and against the default path itself."""
+    from arxiv_rag_amd.encoder import HipEncoder
+    g = np.load(golden_dir / "full_shapes.npz")
+    key, cfg = "all-mpnet-base-v2:w05", C.MPNET_BASE
+    seed, std, bstd, jit = g[key + ":wspec"]
+    sd = seeded_state_dict(cfg, seed=int(seed), std=std, bias_std=bstd, ln_jitter=jit)
+    ids, lens, ref = g[key + ":ids"], g[key + ":lens"], g[key + ":emb"]
+    base = HipEncoder(cfg, sd)
+    e0 = base.encode_tokens(ids, lens).cpu().numpy()
+    base.close()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = HipEncoder(cfg, sd)
+    e1 = alt.encode_tokens(ids, lens).cpu().numpy()
+    alt.close()
+    assert _cos(e1, ref).min() > 1 - 1e-3
+    assert _cos(e1, e0).min() > 1 - 3e-4
