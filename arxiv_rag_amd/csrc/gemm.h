@@ -31,7 +31,7 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 // Stage a [ROWS x 64-element] tile (rows row0.., columns k0..k0+63 of G[ld]) into `tile` (LDS).
-template <int ROWS, int NT, bool GLDS, int XOPT = 0>
+template <int ROWS, int NT, bool GLDS>
 __device__ __forceinline__ void stage_issue(const uint16_t* __restrict__ G, int64_t ld, int row0, int row_max,
                                             int k0, char* tile, int tid, u32x4 (&regs)[ROWS * 8 / NT]) {
     constexpr int IT = ROWS * 8 / NT;
@@ -40,10 +40,9 @@ __device__ __forceinline__ void stage_issue(const uint16_t* __restrict__ G, int6
     for (int it = 0; it < IT; ++it) {
         const int cid = it * NT + tid;
         const int row = cid >> 3, pc = cid & 7;
-        const int c = (XOPT & 32) ? pc : (pc ^ ((row >> 1) & 7));
+        const int c = pc ^ ((row >> 1) & 7);
         int grow = row0 + row;
         grow = grow < row_max ? grow : row_max;
-        if constexpr (XOPT & 16) grow &= 1023;          // ABLATION: all tiles read the same 1024 rows (cache-resident)
         const uint16_t* src = G + (int64_t)grow * ld + k0 + c * 8;
         if constexpr (GLDS) {
             char* dst = tile + (it * NT + (tid & ~63)) * 16;      // wave-uniform base; lane l lands at +16*l
@@ -62,9 +61,9 @@ __device__ __forceinline__ void stage_commit(char* tile, int tid, const u32x4 (&
 
 // Main loop: fills acc[NI][MI] for the block tile at (m0, n0).
 //   acc[j][i][r]:  n = n0 + wn*TN + j*16 + (lane>>4)*4 + r ,  m = m0 + wm*TM + i*16 + (lane&15)
-// OPT bits (experiments): 1 = waves in the upper half issue next-stage loads mid-step (stagger),
-//   2 = s_setprio(1) around MFMA clusters, 4 = ABLATION no global loads after the prologue,
-//   8 = ABLATION no MFMA (fragments kept alive)
+// OPT bits: 1 = waves in the upper half issue the next stage's loads after their first MFMA cluster (stagger),
+//   2 = s_setprio(1) around MFMA clusters, 64 = rotate the k-loop start by 2*tile_n (set by the kernel),
+//   4096 = register double-buffered fragments (variant 34)
 template <typename T, int BM, int BN, int WM, int WN, bool GLDS, int OPT = 0>
 struct GemmMainloop {
     static constexpr int NT = WM * WN * 64;
@@ -97,8 +96,8 @@ struct GemmMainloop {
         // share an A panel start at different k so that they do not all miss on the same lines at once
         koff = koff % nk;
         auto kstep = [&](int kt) { int k = kt + koff; return (k >= nk ? k - nk : k) << 6; };
-        stage_issue<BM, NT, GLDS, OPT>(Ag, lda, m0, M - 1, kstep(0), smem, tid, ra);
-        stage_issue<BN, NT, GLDS, (OPT & ~16)>(Wg, ldw, n0, N - 1, kstep(0), smem + A_BYTES, tid, rw);
+        stage_issue<BM, NT, GLDS>(Ag, lda, m0, M - 1, kstep(0), smem, tid, ra);
+        stage_issue<BN, NT, GLDS>(Wg, ldw, n0, N - 1, kstep(0), smem + A_BYTES, tid, rw);
         if constexpr (!GLDS) {
             stage_commit<BM, NT>(smem, tid, ra);
             stage_commit<BN, NT>(smem + A_BYTES, tid, rw);
@@ -127,8 +126,8 @@ struct GemmMainloop {
                 const char* cur = smem + (kt & 1) * STAGE_BYTES;
                 char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
                 if (kt + 1 < nk) {
-                    stage_issue<BM, NT, GLDS, OPT>(Ag, lda, m0, M - 1, kstep(kt + 1), nxt, tid, ra);
-                    stage_issue<BN, NT, GLDS, (OPT & ~16)>(Wg, ldw, n0, N - 1, kstep(kt + 1), nxt + A_BYTES, tid, rw);
+                    stage_issue<BM, NT, GLDS>(Ag, lda, m0, M - 1, kstep(kt + 1), nxt, tid, ra);
+                    stage_issue<BN, NT, GLDS>(Wg, ldw, n0, N - 1, kstep(kt + 1), nxt + A_BYTES, tid, rw);
                 }
                 rd(cur, off0, af0, wf0);                 // first cluster's fragments of this step
                 if (kt > 0) mm(af1, wf1);                // second cluster of the previous step
@@ -143,9 +142,9 @@ struct GemmMainloop {
             char* cur = smem + (kt & 1) * STAGE_BYTES;
             char* nxt = smem + ((kt + 1) & 1) * STAGE_BYTES;
             const bool late = (OPT & 1) && (__builtin_amdgcn_readfirstlane(wid) >= (WM * WN) / 2);
-            if (kt + 1 < nk && !(OPT & 4) && !late) {
-                stage_issue<BM, NT, GLDS, OPT>(Ag, lda, m0, M - 1, kstep(kt + 1), nxt, tid, ra);
-                stage_issue<BN, NT, GLDS, (OPT & ~16)>(Wg, ldw, n0, N - 1, kstep(kt + 1), nxt + A_BYTES, tid, rw);
+            if (kt + 1 < nk && !late) {
+                stage_issue<BM, NT, GLDS>(Ag, lda, m0, M - 1, kstep(kt + 1), nxt, tid, ra);
+                stage_issue<BN, NT, GLDS>(Wg, ldw, n0, N - 1, kstep(kt + 1), nxt + A_BYTES, tid, rw);
             }
             const char* As = cur + a_base;
             const char* Ws = cur + A_BYTES + w_base;
@@ -157,22 +156,15 @@ struct GemmMainloop {
                 for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec*>(As + i * 2048 + off);
 #pragma unroll
                 for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const vec*>(Ws + j * 2048 + off);
-                if constexpr (OPT & 8) {
+                if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+                for (int j = 0; j < NI; ++j)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(wf[j]));
-                } else {
-                    if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-#pragma unroll
-                        for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<T>::mma(wf[j], af[i], acc[j][i]);
-                    if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(0);
-                }
-                if (ks == 0 && late && kt + 1 < nk && !(OPT & 4)) {
-                    stage_issue<BM, NT, GLDS, OPT>(Ag, lda, m0, M - 1, kstep(kt + 1), nxt, tid, ra);
-                    stage_issue<BN, NT, GLDS, (OPT & ~16)>(Wg, ldw, n0, N - 1, kstep(kt + 1), nxt + A_BYTES, tid, rw);
+                    for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<T>::mma(wf[j], af[i], acc[j][i]);
+                if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(0);
+                if (ks == 0 && late && kt + 1 < nk) {
+                    stage_issue<BM, NT, GLDS>(Ag, lda, m0, M - 1, kstep(kt + 1), nxt, tid, ra);
+                    stage_issue<BN, NT, GLDS>(Wg, ldw, n0, N - 1, kstep(kt + 1), nxt + A_BYTES, tid, rw);
                 }
             }
             if constexpr (!GLDS) {
@@ -353,26 +345,19 @@ struct GemmRing {
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();          // everyone's part of h landed; everyone done reading slot (h-1)
             __builtin_amdgcn_sched_barrier(0);
-            if (!(OPT & 4) && h + DEPTH < nh) issue(Ag, lda, M, Wg, ldw, N, m0, n0, h + DEPTH, smem, tid);
+            if (h + DEPTH < nh) issue(Ag, lda, M, Wg, ldw, N, m0, n0, h + DEPTH, smem, tid);
             const char* slot = smem + (h % SLOTS) * SLOT_BYTES;
             vec af[MI], wf[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const vec*>(slot + a_base + i * 1024);
 #pragma unroll
             for (int j = 0; j < NI; ++j) wf[j] = *reinterpret_cast<const vec*>(slot + w_base + j * 1024);
-            if constexpr (OPT & 8) {
+            if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+            for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(wf[j]));
-            } else {
-                if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-#pragma unroll
-                    for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<T>::mma(wf[j], af[i], acc[j][i]);
-                if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(0);
-            }
+                for (int i = 0; i < MI; ++i) acc[j][i] = Mfma<T>::mma(wf[j], af[i], acc[j][i]);
+            if constexpr (OPT & 2) __builtin_amdgcn_s_setprio(0);
         }
     }
 };
@@ -540,7 +525,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_v0e2_kernel(const bf16_t* _
     const int tile_m = t / tiles_n, tile_n = t % tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     f32x4 acc[ML::NI][ML::MI];
-    const int koff = (OPT & 64) ? tile_n * 2 : ((OPT & 128) ? tile_n : ((OPT & 256) ? tile_n * 4 : 0));
+    const int koff = (OPT & 64) ? tile_n * 2 : 0;
     ML::run(A, lda, M, W, ldw, N, K, m0, n0, smem, acc, koff);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     epilogue_store_v2<MODE, ML::NI, ML::MI>(acc, ep, m0 + (wid / WN) * ML::TM, n0 + (wid % WN) * ML::TN, lane, M, N);
@@ -584,8 +569,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_a3w2_kernel(const bf16_t* _
     const int koff = (tile_n * KROT) % nk;
     auto kcol = [&](int kt) { int k = kt + koff; return (k >= nk ? k - nk : k) << 6; };
     u32x4 dummy_a[LA], dummy_w[LW];
-    auto issueA = [&](int kt) { stage_issue<BM, NT, true, 0>(Ag, lda, m0, M - 1, kcol(kt), Abuf + (kt % 3) * A_BYTES, tid, dummy_a); };
-    auto issueW = [&](int kt) { stage_issue<BN, NT, true, 0>(Wg, ldw, n0, N - 1, kcol(kt), Wbuf + (kt & 1) * W_BYTES, tid, dummy_w); };
+    auto issueA = [&](int kt) { stage_issue<BM, NT, true>(Ag, lda, m0, M - 1, kcol(kt), Abuf + (kt % 3) * A_BYTES, tid, dummy_a); };
+    auto issueW = [&](int kt) { stage_issue<BN, NT, true>(Wg, ldw, n0, N - 1, kcol(kt), Wbuf + (kt & 1) * W_BYTES, tid, dummy_w); };
     f32x4 acc[NI][MI];
 #pragma unroll
     for (int j = 0; j < NI; ++j)
