@@ -371,3 +371,24 @@ def test_alternative_schedules_agree(hip, golden_dir, env, monkeypatch):
     alt.close()
     assert _cos(e1, ref).min() > 1 - 1e-3
     assert _cos(e1, e0).min() > 1 - 3e-4
+
+
+@pytest.mark.parametrize("name,lens", [("all-MiniLM-L6-v2", [512, 400, 300, 257, 511, 33]),
+                                       ("all-mpnet-base-v2", [384, 300, 257, 383, 5])])
+def test_long_sequences_vs_oracle(hip, name, lens):
+    """Sequences beyond 256 tokens (all-mpnet-base-v2 truncates at 384, BERT-style models at 512): attention runs two
+    query blocks per (sequence, head) over up to 16 key tiles, LDS holds 512-key K/V; against the fp32 oracle."""
+    from arxiv_rag_amd.encoder import HipEncoder
+    cfg = C.PRESETS[name]
+    sd = seeded_state_dict(cfg, seed=8, std=0.04, bias_std=0.02, ln_jitter=0.05)
+    rs = np.random.RandomState(3)
+    lens = np.array(lens, np.int64)
+    S = int(lens.max())
+    ids = np.full((len(lens), S), cfg.pad_id, np.int64)
+    for r, n in enumerate(lens):
+        ids[r, :n] = rs.randint(4, cfg.vocab_size - 1, size=n)
+    ref = EO.encode_tokens(sd, cfg, ids, lens)
+    enc = HipEncoder(cfg, sd)
+    emb = enc.encode_tokens(ids, lens).cpu().numpy()
+    assert _cos(emb, ref).min() > 1 - 1e-3
+    enc.close()
