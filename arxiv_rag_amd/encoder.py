@@ -146,23 +146,40 @@ class HipEncoder:
         d_lens = torch.from_numpy(lens).to(self.device, non_blocking=True)
         return self.forward_tokens(d_ids, d_lens, max_len, total, normalize=normalize)
 
+    @staticmethod
+    def _pad_batch(seqs: Sequence[Sequence[int]], idx: Sequence[int], pad_id: int):
+        """Right-padded int32 [len(idx), S] + lens, built with one concatenate and one fancy assignment."""
+        lens = np.fromiter((len(seqs[i]) for i in idx), np.int32, len(idx))
+        S = max(int(lens.max()) if len(idx) else 1, 1)
+        ids = np.full((len(idx), S), pad_id, np.int32)
+        tot = int(lens.sum())
+        if tot:
+            flat = np.concatenate([np.asarray(seqs[i], np.int32) for i in idx if len(seqs[i])])
+            rows = np.repeat(np.arange(len(idx)), lens)
+            starts = np.cumsum(lens) - lens
+            cols = np.arange(tot) - np.repeat(starts, lens)
+            ids[rows, cols] = flat
+        return ids, lens
+
     def encode_ragged(self, seqs: Sequence[Sequence[int]], batch_size: int = 256, normalize: bool = True) -> np.ndarray:
         """Token-id lists -> f32 [n, H] numpy, input order preserved.  Sorted by length (descending, as
         sentence-transformers does) so each forward pads to a similar length; results do not depend on
-        batch composition (key-padding mask), so the re-bucketing is invisible to the caller."""
+        batch composition (key-padding mask), so the re-bucketing is invisible to the caller.  All forwards of the
+        call are queued on the stream and the rows come back with ONE device->host copy."""
         n = len(seqs)
-        out = np.zeros((n, self.cfg.hidden), np.float32)
         if n == 0:
-            return out
+            return np.zeros((0, self.cfg.hidden), np.float32)
         order = sorted(range(n), key=lambda i: -len(seqs[i]))
+        dev_out = torch.empty((n, self.cfg.hidden), dtype=torch.float32, device=self.device)
         for s0 in range(0, n, batch_size):
             idx = order[s0:s0 + batch_size]
-            lens = np.array([len(seqs[i]) for i in idx], np.int32)
-            S = max(int(lens.max()), 1)
-            ids = np.full((len(idx), S), self.cfg.pad_id, np.int32)
-            for r, i in enumerate(idx):
-                ids[r, :lens[r]] = seqs[i]
-            out[idx] = self.encode_tokens(ids, lens, normalize).cpu().numpy()
+            ids, lens = self._pad_batch(seqs, idx, self.cfg.pad_id)
+            d_ids = torch.from_numpy(ids).to(self.device, non_blocking=True)
+            d_lens = torch.from_numpy(lens).to(self.device, non_blocking=True)
+            self.forward_tokens(d_ids, d_lens, ids.shape[1], max(int(lens.sum()), 1), out=dev_out[s0:s0 + len(idx)],
+                                normalize=normalize)
+        out = np.empty((n, self.cfg.hidden), np.float32)
+        out[np.asarray(order)] = dev_out.cpu().numpy()
         return out
 
     def tap_hidden(self, ids: np.ndarray, lens: np.ndarray, layer: int) -> np.ndarray:
@@ -190,6 +207,7 @@ class HipSentenceEncoder:
         self.max_seq_length = cfg.max_seq_length
         self.encoder = HipEncoder(cfg, state_dict, device=device)
         self.max_batch = max_batch
+        self.slab_texts = 8192          # texts tokenised per feeder step
 
     def get_sentence_embedding_dimension(self) -> int:
         return self.cfg.hidden
@@ -202,9 +220,23 @@ class HipSentenceEncoder:
         single = isinstance(sentences, str)
         if single:
             sentences = [sentences]
-        seqs = self.tokenize(sentences)
-        emb = self.encoder.encode_ragged(seqs, batch_size=max(1, min(batch_size, self.max_batch)),
-                                         normalize=normalize_embeddings)
+        sentences = list(sentences)
+        bs = max(1, min(batch_size, self.max_batch))
+        slab = max(bs, self.slab_texts)
+        if len(sentences) <= slab:
+            emb = self.encoder.encode_ragged(self.tokenize(sentences), batch_size=bs, normalize=normalize_embeddings)
+        else:
+            # feeder: the tokenizer (Rust, releases the GIL) works on slab i+1 in a helper thread while the GPU encodes slab i
+            from concurrent.futures import ThreadPoolExecutor
+            parts = []
+            with ThreadPoolExecutor(max_workers=1) as ex:
+                fut = ex.submit(self.tokenize, sentences[:slab])
+                for s0 in range(0, len(sentences), slab):
+                    seqs = fut.result()
+                    if s0 + slab < len(sentences):
+                        fut = ex.submit(self.tokenize, sentences[s0 + slab:s0 + 2 * slab])
+                    parts.append(self.encoder.encode_ragged(seqs, batch_size=bs, normalize=normalize_embeddings))
+            emb = np.concatenate(parts, 0)
         if convert_to_tensor:
             emb = torch.from_numpy(emb)
         return emb[0] if single else emb
