@@ -52,6 +52,7 @@ EXPORTS = {
                                    C.c_void_p]),
     "arx_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
+    "arx_adjacent_cosine": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "arx_f32_to_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "arx_fill_unit_rows_f16": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_void_p]),
     "arx_prof_enable": (C.c_int32, [C.c_int32]),

@@ -524,6 +524,15 @@ extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32
     return ARX_OK;
 }
 
+extern "C" int32_t arx_adjacent_cosine(const float* emb, int64_t ld, int32_t n, int32_t dim, float* out, void* stream) {
+    ARX_REQUIRE(n >= 0 && dim > 0 && dim % 4 == 0 && ld >= dim, "bad sizes (dim must be a multiple of 4)");
+    if (n < 2) return ARX_OK;   // no pairs: out may be an empty (null) buffer
+    ARX_REQUIRE(emb && out, "null pointer argument");
+    adjacent_cosine_kernel<<<cdiv(n - 1, 4), 256, 0, (hipStream_t)stream>>>(emb, ld, n, dim, out);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
 extern "C" int32_t arx_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
     ARX_REQUIRE(src && dst && n >= 0, "bad args");
     if (n == 0) return ARX_OK;

@@ -668,6 +668,25 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(const uint16_t* __restrict
     if (lane == 0) { s[n] = ss; c[n] = bias[n] + cc; }
 }
 
+// cos(e_i, e_{i+1}) for consecutive rows of an f32 matrix: the similarity the stage-3 semantic chunker thresholds at 0.7
+// (text_processor.py:1555-1561, _cosine_similarity :1601-1605 = dot / (|a| |b|)).  One wave per pair.
+__global__ __launch_bounds__(256) void adjacent_cosine_kernel(const float* __restrict__ e, int64_t ld, int n, int D,
+                                                               float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i + 1 >= n) return;
+    const float* a = e + (int64_t)i * ld;
+    const float* b = a + ld;
+    float dot = 0.f, na = 0.f, nb = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a + c), y = *reinterpret_cast<const f32x4*>(b + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dot = fmaf(x[r], y[r], dot); na = fmaf(x[r], x[r], na); nb = fmaf(y[r], y[r], nb); }
+    }
+    dot = wave_sum(dot); na = wave_sum(na); nb = wave_sum(nb);
+    if (lane == 0) out[i] = dot / (sqrtf(na) * sqrtf(nb));
+}
+
 // bf16 [n, H] -> f32 (debug tap)
 __global__ void bf16_to_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

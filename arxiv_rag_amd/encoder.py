@@ -161,14 +161,17 @@ class HipEncoder:
             ids[rows, cols] = flat
         return ids, lens
 
-    def encode_ragged(self, seqs: Sequence[Sequence[int]], batch_size: int = 256, normalize: bool = True) -> np.ndarray:
+    def encode_ragged(self, seqs: Sequence[Sequence[int]], batch_size: int = 256, normalize: bool = True,
+                      on_device: bool = False):
         """Token-id lists -> f32 [n, H] numpy, input order preserved.  Sorted by length (descending, as
         sentence-transformers does) so each forward pads to a similar length; results do not depend on
         batch composition (key-padding mask), so the re-bucketing is invisible to the caller.  All forwards of the
-        call are queued on the stream and the rows come back with ONE device->host copy."""
+        call are queued on the stream and the rows come back with ONE device->host copy (`on_device=True`: no copy,
+        a device tensor in input order, for a consumer that also lives on the GPU)."""
         n = len(seqs)
         if n == 0:
-            return np.zeros((0, self.cfg.hidden), np.float32)
+            return (torch.zeros((0, self.cfg.hidden), dtype=torch.float32, device=self.device) if on_device
+                    else np.zeros((0, self.cfg.hidden), np.float32))
         order = sorted(range(n), key=lambda i: -len(seqs[i]))
         dev_out = torch.empty((n, self.cfg.hidden), dtype=torch.float32, device=self.device)
         for s0 in range(0, n, batch_size):
@@ -178,6 +181,10 @@ class HipEncoder:
             d_lens = torch.from_numpy(lens).to(self.device, non_blocking=True)
             self.forward_tokens(d_ids, d_lens, ids.shape[1], max(int(lens.sum()), 1), out=dev_out[s0:s0 + len(idx)],
                                 normalize=normalize)
+        if on_device:
+            out = torch.empty_like(dev_out)
+            out[torch.as_tensor(order, device=self.device)] = dev_out
+            return out
         out = np.empty((n, self.cfg.hidden), np.float32)
         out[np.asarray(order)] = dev_out.cpu().numpy()
         return out
@@ -192,6 +199,19 @@ class HipEncoder:
                                                      torch.cuda.current_stream().cuda_stream), "arx_encoder_debug_hidden")
         _lib.check(self.lib.arx_encoder_set_tap(self._handle, -1), "arx_encoder_set_tap")
         return dst.cpu().numpy()
+
+
+def adjacent_cosines(embeddings: torch.Tensor) -> torch.Tensor:
+    """cos(e_i, e_{i+1}) for consecutive rows (device f32 [n, D] -> [n-1]) — the similarity the stage-3 semantic
+    chunker breaks on when it drops below 0.7 (text_processor.py:1555-1561)."""
+    lib = _lib.load()
+    e = embeddings
+    assert e.is_cuda and e.dtype == torch.float32 and e.dim() == 2 and e.stride(1) == 1
+    n, d = e.shape
+    out = torch.empty((max(n - 1, 0),), dtype=torch.float32, device=e.device)
+    _lib.check(lib.arx_adjacent_cosine(e.data_ptr(), e.stride(0), n, d, out.data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream), "arx_adjacent_cosine")
+    return out
 
 
 class HipSentenceEncoder:
@@ -214,6 +234,12 @@ class HipSentenceEncoder:
 
     def tokenize(self, sentences: Sequence[str]) -> List[List[int]]:
         return self.tokenizer.encode_batch(list(sentences), self.max_seq_length)
+
+    def encode_device(self, sentences: Sequence[str], batch_size: int = 32, normalize_embeddings: bool = False) -> torch.Tensor:
+        """Rows stay in HBM (f32 [n, D], input order) — for GPU-side consumers (adjacent cosine, the search index)."""
+        bs = max(1, min(batch_size, self.max_batch))
+        return self.encoder.encode_ragged(self.tokenize(list(sentences)), batch_size=bs, normalize=normalize_embeddings,
+                                          on_device=True)
 
     def encode(self, sentences, batch_size: int = 32, show_progress_bar=None, convert_to_numpy: bool = True,
                convert_to_tensor: bool = False, normalize_embeddings: bool = False, **_ignored):

@@ -146,6 +146,11 @@ int32_t arx_topk_merge(const float* scores, const int64_t* ids, int32_t n_parts,
 int32_t arx_gemm_bf16(const void* A, const void* W, const float* bias, const void* resid, void* C,
                       int32_t M, int32_t N, int32_t K, int32_t mode, int32_t variant, void* stream);
 
+/* out[i] = cos(emb[i], emb[i+1]) for i in [0, n-1): the adjacent-sentence similarity the stage-3 semantic chunker
+ * thresholds (/root/reference/3-chunks/pipeline/src/processors/text_processor.py:1555-1561, helper :1601-1605).
+ * emb device f32 [n, ld >= dim]; out device f32 [n-1]. */
+int32_t arx_adjacent_cosine(const float* emb, int64_t ld, int32_t n, int32_t dim, float* out, void* stream);
+
 /* ---- small device helpers the host code needs (all on `stream`) -------------------------------- */
 /* f32 [n] -> bf16 [n] round-to-nearest-even (weight upload). */
 int32_t arx_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);

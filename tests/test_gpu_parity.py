@@ -392,3 +392,107 @@ def test_long_sequences_vs_oracle(hip, name, lens):
     emb = enc.encode_tokens(ids, lens).cpu().numpy()
     assert _cos(emb, ref).min() > 1 - 1e-3
     enc.close()
+
+
+def test_adjacent_cosine_vs_reference_helper(hip):
+    """second client of the encoder: adjacent-sentence cosine, against the reference's
+    _cosine_similarity restated in the oracle (text_processor.py:1601-1605)."""
+    from arxiv_rag_amd.encoder import adjacent_cosines
+    rs = np.random.RandomState(0)
+    for n, d in ((1, 384), (2, 384), (57, 384), (300, 768)):
+        e = rs.standard_normal((n, d)).astype(np.float32) * rs.uniform(0.1, 3, size=(n, 1)).astype(np.float32)
+        got = adjacent_cosines(torch.from_numpy(e).cuda()).cpu().numpy()
+        want = np.array([EO.cosine_similarity(e[i], e[i + 1]) for i in range(n - 1)], np.float32)
+        assert got.shape == want.shape and (n < 2 or np.abs(got - want).max() < 1e-5)
+
+
+def test_semantic_chunker_gpu_similarities_give_reference_chunks(hip):
+    """fixture embeddings -> arx_adjacent_cosine -> host grouping == the chunks the reference's loop produced."""
+    import json
+    from pathlib import Path
+    from arxiv_rag_amd.encoder import adjacent_cosines
+    from arxiv_rag_amd.semantic import group_sentences
+    fx = json.loads((Path(__file__).parent / "golden" / "semantic_chunker.json").read_text(encoding="utf-8"))
+    for c in fx["cases"]:
+        e = torch.tensor(c["embeddings"], dtype=torch.float32, device="cuda")
+        sims = adjacent_cosines(e).cpu().numpy()
+        assert np.abs(sims - np.array(c["similarities"], np.float32)).max() < 1e-5
+        assert group_sentences(c["sentences"], sims, c["max_chunk_size"], c["min_chunk_size"], c["metadata"]) == c["expected_chunks"]
+
+
+# ------------------------------------------------------------------ text in, files out: the drop-in script on the GPU
+def _tiny_text_models():
+    from arxiv_rag_amd import config as CFG
+    from arxiv_rag_amd.encoder import HipSentenceEncoder
+    from arxiv_rag_amd.tokenizer import WordPieceTokenizer
+    from arxiv_rag_amd.weights import seeded_state_dict
+    from tests.helpers import OracleSentenceModel, synthetic_vocab
+    cfg = CFG.TINY_BERT
+    sd = seeded_state_dict(cfg, seed=4, std=0.05)
+    tok = WordPieceTokenizer.from_vocab(synthetic_vocab(cfg), cfg)
+    return cfg, HipSentenceEncoder(cfg, sd, tok), OracleSentenceModel(cfg, sd, tok)
+
+
+def test_cli_text_to_files_gpu_vs_oracle_model(hip, tmp_path, monkeypatch):
+    """Same CLI, same chunk tree, the HIP sentence encoder vs the oracle-backed stand-in: identical metadata/index
+    files, embeddings within the parity bar (cosine >= 1 - 1e-3), for both --embedding-workers paths."""
+    import json
+    from arxiv_rag_amd import generate_embeddings_parallel as GEN
+    from tests.helpers import make_chunk_tree
+    cfg, hipm, orm = _tiny_text_models()
+    make_chunk_tree(tmp_path / "in", n_files=6, chunks_per_file=7, seed=2)
+    outs = {}
+    for tag, model in (("hip", hipm), ("oracle", orm)):
+        monkeypatch.chdir(tmp_path)
+        (tmp_path / tag).mkdir()
+        monkeypatch.chdir(tmp_path / tag)
+        rc = GEN.main([str(tmp_path / "in"), "--min-quality", "0.0", "--skip-chroma", "--batch-size", "16"],
+                      model_factory=lambda name, m=model: m)
+        assert rc == 0
+        d = tmp_path / tag / "embeddings_saved"
+        outs[tag] = (np.load(d / "embeddings.npy"), (d / "metadata.json").read_bytes(), json.loads((d / "index.json").read_text()))
+    eh, mh, ih = outs["hip"]; eo, mo, io_ = outs["oracle"]
+    assert mh == mo and ih == io_
+    assert eh.dtype == eo.dtype == np.float64 and eh.shape == eo.shape and eh.shape[0] > 0
+    assert min(_cos(eh[i], eo[i]) for i in range(len(eh))) >= 1 - 1e-3
+    hipm.encoder.close()
+
+
+def test_encode_feeder_slabs_and_device_rows(hip):
+    """encode(): the multi-slab feeder path returns the same rows as one slab; encode_device keeps input order."""
+    cfg, hipm, orm = _tiny_text_models()
+    rs = np.random.RandomState(5)
+    words = ["ab", "cd", "graph", "x", "lattice", "qed", "zz"]
+    texts = [" ".join(rs.choice(words, size=rs.randint(1, 30))) for _ in range(300)] + [""]
+    one = hipm.encode(texts, batch_size=32, normalize_embeddings=True)
+    hipm.slab_texts = 64
+    many = hipm.encode(texts, batch_size=32, normalize_embeddings=True)
+    assert np.array_equal(one, many)
+    dev = hipm.encode_device(texts, batch_size=32, normalize_embeddings=True)
+    assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), one)
+    want = orm.encode(texts, batch_size=32, normalize_embeddings=True)
+    assert min(_cos(one[i], want[i]) for i in range(len(texts))) >= 1 - 1e-3
+    hipm.encoder.close()
+
+
+def test_semantic_chunks_end_to_end_vs_oracle_model(hip):
+    """sentence split -> HIP encode (un-normalised) -> arx_adjacent_cosine -> grouping, against the same walk fed by
+    the oracle model and the reference's numpy cosine; similarities within 2e-3 of the 0.7 threshold are excluded
+    from the chunk comparison (bf16 encoder vs fp32 oracle)."""
+    from arxiv_rag_amd.semantic import group_sentences, semantic_chunks, split_sentences
+    from arxiv_rag_amd.encoder import adjacent_cosines
+    cfg, hipm, orm = _tiny_text_models()
+    rs = np.random.RandomState(9)
+    words = ["graph", "neural", "lattice", "qed", "proof", "of", "the", "bounded", "spectrum", "we", "show"]
+    text = " ".join(" ".join(rs.choice(words, size=rs.randint(4, 25))).capitalize() + "." for _ in range(80))
+    sents = split_sentences(text)
+    eo = orm.encode(sents, normalize_embeddings=False)
+    so = np.array([EO.cosine_similarity(eo[i], eo[i - 1]) for i in range(1, len(sents))])
+    sh = adjacent_cosines(hipm.encode_device(sents)).cpu().numpy()
+    assert np.abs(sh - so).max() < 2e-3
+    assert semantic_chunks("Too short.", hipm) is None
+    got = semantic_chunks(text, hipm, max_chunk_size=600, min_chunk_size=50, metadata={"paper_id": "p"})
+    assert got and all(c["metadata"]["chunk_method"] == "semantic" for c in got)
+    if np.abs(so - 0.7).min() > 2e-3:
+        assert got == group_sentences(sents, so, 600, 50, {"paper_id": "p"})
+    hipm.encoder.close()

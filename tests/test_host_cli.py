@@ -298,3 +298,18 @@ def test_load_embeddings_from_disk_both_layouts(tmp_path):
     assert np.allclose(e2, embs) and [x["chunk_id"] for x in m2] == [f"c{j}" for j in range(25)]
     e3, m3 = load_embeddings_from_disk(b, batch_index=2)
     assert e3.shape == (5, 8) and m3[0]["chunk_id"] == "c20"
+
+
+def test_semantic_grouping_matches_reference_walk():
+    """group_sentences / split_sentences against chunks produced by the reference's own loop
+    (text_processor.py:1275-1276, 1542-1599; fixture from tools/make_golden.py `semantic`)."""
+    from arxiv_rag_amd.semantic import group_sentences, split_sentences
+    fx = json.loads((Path(__file__).parent / "golden" / "semantic_chunker.json").read_text(encoding="utf-8"))
+    assert split_sentences(fx["split"]["text"]) == fx["split"]["expected"]
+    assert len(fx["cases"]) >= 7
+    for c in fx["cases"]:
+        got = group_sentences(c["sentences"], c["similarities"], c["max_chunk_size"], c["min_chunk_size"], c["metadata"])
+        assert got == c["expected_chunks"]
+    assert group_sentences([], []) == []
+    with pytest.raises(ValueError):
+        group_sentences(["a", "b"], [])

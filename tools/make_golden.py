@@ -229,10 +229,57 @@ def gen_harness():
     print("harness fixtures:", len(chunks), "chunks kept")
 
 
+def gen_semantic():
+    """Run the reference's own sentence split (:1275-1276) and grouping walk (:1542-1599, cosine helper :1601-1605)
+    on synthetic sentences + embeddings; the encode in between is the GPU path and is not part of this fixture."""
+    tp = GEN.parents[2] / "3-chunks/pipeline/src/processors/text_processor.py"
+    if not tp.exists():
+        print("reference absent; skipping semantic fixtures"); return
+    lines = tp.read_text().splitlines(keepends=True)
+    src = ("import re\nclass R:\n"
+           "    def __init__(self, lo, hi):\n        self.min_chunk_size, self.max_chunk_size = lo, hi\n"
+           "    def split(self, text):\n" + _extract(lines, 1275, 1276) + "        return sentences\n"
+           "    def group(self, sentences, embeddings, metadata=None):\n" + _extract(lines, 1542, 1599)
+           + _extract(lines, 1601, 1605))
+    ns = {}
+    exec(compile(src, "text_processor.py:1275-1276,1542-1605", "exec"), ns)
+    R = ns["R"]
+    rs = np.random.RandomState(11)
+    words = ["graph", "neural", "network", "quantum", "field", "theory", "we", "show", "that", "the", "results",
+             "lattice", "galaxy", "cluster", "proof", "lemma", "of", "a", "in", "bounded", "operator", "spectrum"]
+    cases = []
+    for ci, (n, lo, hi, rho) in enumerate([(40, 100, 1000, 0.9), (40, 200, 2000, 0.6), (25, 10, 300, 0.8),
+                                            (60, 100, 400, 0.95), (2, 5, 1000, 0.5), (30, 100, 120, 0.9),
+                                            (12, 1, 100000, 0.75)]):
+        sents = []
+        for _ in range(n):
+            k = int(rs.randint(3, 40))
+            sents.append(" ".join(words[j] for j in rs.randint(0, len(words), k)).capitalize() + rs.choice([".", "!", "?"]))
+        d = 16
+        e = np.zeros((n, d), np.float32)
+        e[0] = rs.standard_normal(d)
+        for i in range(1, n):                     # AR(1) walk: neighbouring cosines scatter around rho
+            r = rho if rs.rand() > 0.25 else rs.uniform(-0.2, 0.5)
+            e[i] = r * e[i - 1] / np.linalg.norm(e[i - 1]) + np.sqrt(max(1 - r * r, 0)) * rs.standard_normal(d) / np.sqrt(d)
+            e[i] *= rs.uniform(0.5, 4.0)
+        sims = [float(R._cosine_similarity(e[i], e[i - 1])) for i in range(1, n)]
+        if any(abs(x - 0.7) < 1e-3 for x in sims):
+            raise SystemExit("similarity too close to the threshold; change the seed")
+        md = {"paper_id": f"0704.{ci:04d}", "section": "Introduction"} if ci % 2 == 0 else None
+        chunks = R(lo, hi).group(sents, e, md)
+        cases.append({"min_chunk_size": lo, "max_chunk_size": hi, "metadata": md, "sentences": sents,
+                      "embeddings": e.tolist(), "similarities": sims, "expected_chunks": chunks})
+    text = ("Short one. This sentence is long enough to be kept!  And so is this other one?\nTiny. "
+            "A final sentence without a terminator that is kept as well")
+    out = {"cases": cases, "split": {"text": text, "expected": R(0, 0).split(text)}}
+    (GOLD / "semantic_chunker.json").write_text(json.dumps(out, ensure_ascii=False), encoding="utf-8")
+    print("semantic fixtures:", [len(c["expected_chunks"]) for c in cases], "chunks per case; split ->", out["split"]["expected"])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     GOLD.mkdir(parents=True, exist_ok=True)
-    what = sys.argv[1:] or ["tiny", "tables", "search", "harness", "full"]
+    what = sys.argv[1:] or ["tiny", "tables", "search", "harness", "semantic", "full"]
     for w in what:
         {"tiny": gen_tiny, "full": gen_full, "tables": gen_tables, "search": gen_search,
-         "harness": gen_harness}[w]()
+         "harness": gen_harness, "semantic": gen_semantic}[w]()
