@@ -8,6 +8,7 @@
 #include "arx_common.h"
 #include "encoder_kernels.h"
 #include "gemm.h"
+#include "gemm8.h"
 
 // MPNet / T5 bidirectional bucket (TF modeling_mpnet.py:330-349). rel = key_pos - query_pos.
 // Integer-exact restatement: the float32 expression there lands on the expected side of every
@@ -44,7 +45,7 @@ struct arx_encoder {
     std::vector<float*> s_qkv, c_qkv, s_fc1, c_fc1;
     float *st1_sum = nullptr, *st1_sq = nullptr, *st2_sum = nullptr, *st2_sq = nullptr;   // row mean / rstd of y1 / y2
     float *part_s = nullptr, *part_q = nullptr;                                              // [H/64][tok_pad] partial slabs
-    int variant = 13;
+    int variant = 8;
     int attn_variant = 1;
 };
 
@@ -110,7 +111,7 @@ extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_e
     h->max_seqs = max_seqs;
     h->tok_pad = (int)round_up64(max_tokens, 256);
     const char* e = getenv("ARX_GEMM_VARIANT");
-    h->variant = e ? atoi(e) : 13;
+    h->variant = e ? atoi(e) : 8;
     const char* av = getenv("ARX_ATTN_VARIANT");
     h->attn_variant = av ? atoi(av) : 1;
     const char* g = getenv("ARX_GEMM_GLDS");          // legacy switch: 0 = register-staged reference loop
@@ -266,6 +267,10 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
             return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, false, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, false>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a7);
         }
     }
+    if (variant == 8 && wide && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {      // 4-phase-per-k-tile schedule (gemm8.h)
+        static bool r8 = false;
+        return launch_gemm_kernel(gemm_8phase_kernel<MODE>, Gemm8Phase<bf16_t, 2>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &r8);
+    }
     if (variant == 34 && wide) {      // ping-pong: the two waves of a SIMD half a k-step apart
         static bool r2 = false;
         return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 64 + 4096>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 64 + 4096>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &r2);
@@ -313,6 +318,34 @@ extern "C" int32_t arx_gemm_bf16(const void* A, const void* W, const float* bias
     ARX_REQUIRE(mode != EPI_BIAS_RESID || resid, "mode 2 needs resid");
     EpiParams ep{(uint16_t*)C, N, bias, (const uint16_t*)resid, N};
     hipStream_t st = (hipStream_t)stream;
+#ifdef ARX_STAMP
+    {   // dev build: per-tile cycle stamps of one launch, summarised on stderr
+        static unsigned long long* d = nullptr;
+        const int tiles = cdiv(M, 256) * cdiv(N, 256);
+        if (!d) ARX_HIP_CHECK(hipMalloc(&d, (size_t)8 * 4 * 2 * 65536));
+        if (getenv("ARX_STAMP_DUMP") && tiles <= 65536) {
+            ep.stamps = d;
+            int rc = ARX_ERR_ARG;
+            if (mode == EPI_BIAS) rc = arx_launch_gemm<EPI_BIAS>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
+            if (mode == EPI_BIAS_GELU) rc = arx_launch_gemm<EPI_BIAS_GELU>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
+            if (mode == EPI_BIAS_RESID) rc = arx_launch_gemm<EPI_BIAS_RESID>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
+            ARX_HIP_CHECK(hipStreamSynchronize(st));
+            std::vector<unsigned long long> hbuf((size_t)tiles * 8);
+            ARX_HIP_CHECK(hipMemcpy(hbuf.data(), d, hbuf.size() * 8, hipMemcpyDeviceToHost));
+            double loop[2] = {0, 0}, epi[2] = {0, 0}, pro[2] = {0, 0};
+            unsigned long long tmin = ~0ull, tmax = 0;
+            for (int t = 0; t < tiles; ++t)
+                for (int g = 0; g < 2; ++g) {
+                    const unsigned long long* o = &hbuf[((size_t)t * 2 + g) * 4];
+                    loop[g] += (double)(o[1] - o[3]); epi[g] += (double)(o[2] - o[1]); pro[g] += (double)(o[3] - o[0]);
+                    tmin = o[0] < tmin ? o[0] : tmin; tmax = o[2] > tmax ? o[2] : tmax;
+                }
+            fprintf(stderr, "[stamp] M=%d N=%d K=%d mode=%d tiles=%d: prologue %.0f / %.0f, loop g0 %.0f g1 %.0f clk, epilogue g0 %.0f g1 %.0f clk, span %.0f clk, tiles/CU %.1f\n",
+                    M, N, K, mode, tiles, pro[0] / tiles, pro[1] / tiles, loop[0] / tiles, loop[1] / tiles, epi[0] / tiles, epi[1] / tiles, (double)(tmax - tmin), tiles / 256.0);
+            return rc;
+        }
+    }
+#endif
     ProfScope ps(ARX_K_GEMM_FC1, st);
     switch (mode) {
     case EPI_BIAS: return arx_launch_gemm<EPI_BIAS>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);

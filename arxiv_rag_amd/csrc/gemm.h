@@ -211,6 +211,9 @@ struct EpiParams {
     float* o_sq = nullptr;          // [N/64][o_ld] partial sums of squares
     int64_t o_ld = 0;
     float inv_h = 0.f, eps = 0.f;
+#ifdef ARX_STAMP
+    unsigned long long* stamps = nullptr;   // dev build only: [tiles][4] s_memtime at start / loop entry / loop exit / end (wave 0)
+#endif
 };
 
 

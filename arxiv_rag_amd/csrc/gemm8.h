@@ -1,0 +1,204 @@
+// 256 x 256 x 64 "8-phase" main loop (two k-tiles = eight phases per unrolled iteration in the playbook's naming; here
+// four phases per 64-deep k-tile).  Same tile, MFMA (16x16x32), LDS image ([rows][64 elem], 16-B chunk XOR (row>>1)&7 on the
+// glds SOURCE address) and wave tile (128 x 64, 2 x 4 waves) as the default kernel, but a different schedule:
+//
+//   * the k-tile is staged as FOUR half-tiles of 16 KB (A0, A1, B0, B1), two global_load_lds per thread each; the halves are
+//     interleaved row sets so that every wave needs rows of both:  A half h = block rows {wr*128 + h*64 + [0,64)},
+//     B half g = block columns {wc*64 + g*32 + [0,32)}  -> the wave's output stays a contiguous 128 x 64 rectangle;
+//   * each phase computes ONE quadrant of the wave tile (64 x 32 outputs x K=64 = 16 MFMAs) from register fragments, loads
+//     the fragments the next quadrant is missing (phase 1: B-sub0 + A-sub0 = 12 ds_read_b128, 2: B-sub1 = 4, 3: A-sub1 = 8,
+//     4: none) and issues ONE half-tile of prefetch;
+//   * the prefetch stream B0 A0 B1 A1 runs three half-tiles ahead behind ONE counted s_waitcnt vmcnt(6) per k-tile (phase 4)
+//     and raw s_barriers — never vmcnt(0) in the loop;
+//   * the four waves with wr == 1 run one barrier interval behind the four with wr == 0 (waves w and w+4 share a SIMD):
+//     while one wave of a SIMD is in its MFMA section the other is in its ds_read / glds section.
+//
+// Hazards (phase p = load section L(p), barrier, MFMA section, barrier; group 1 is one barrier late):
+//   RAW  a half-tile is readable one phase after the counted wait that retires it (wait before phase 4's first barrier ->
+//        read from phase 1 of the next k-tile);
+//   WAR  a slot is restaged >= 2 phases after its last ds_read, or 1 phase after when an lgkmcnt before the reading phase's
+//        first barrier retired those reads (B-sub0: lgkmcnt(8) in phase 1 -> B0 restaged in phase 2);
+//        A0 (read in 1) restaged in 3, B1 (read in 2) in 4, A1 (read in 3) in phase 1 of the next k-tile.
+#pragma once
+#include "gemm.h"
+
+#ifdef ARX_STAMP
+#define g_stamp1 stamp1_ref
+#endif
+template <typename T, int KROT>
+struct Gemm8Phase {
+    static constexpr int BM = 256, BN = 256, NT = 512, MI = 8, NI = 4;
+    static constexpr int HALF_BYTES = 128 * 128, BUF_BYTES = 4 * HALF_BYTES, SMEM_BYTES = 2 * BUF_BYTES;
+    using vec = typename Mfma<T>::vec;
+
+    static __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
+    static __device__ __forceinline__ void bar() {
+        fence(); __builtin_amdgcn_s_barrier(); fence();
+    }
+
+    static __device__ __forceinline__ void run(const T* __restrict__ A, int64_t lda, int M, const T* __restrict__ W,
+                                               int64_t ldw, int N, int K, int m0, int n0, char* smem,
+                                               f32x4 (&acc)[NI][MI], int koff
+#ifdef ARX_STAMP
+                                               , unsigned long long& stamp1_ref
+#endif
+                                               ) {
+        const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+        const int wr = wid >> 2, wc = wid & 3;
+        const uint16_t* Ag = reinterpret_cast<const uint16_t*>(A);
+        const uint16_t* Wg = reinterpret_cast<const uint16_t*>(W);
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // per-thread source element offsets of its two 16-B pieces of every half-tile (k column added per k-tile)
+        uint32_t aoff[2][2], boff[2][2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int cid = it * NT + tid, r = cid >> 3, c = (cid & 7) ^ ((r >> 1) & 7);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int gm = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+                gm = gm < M ? gm : M - 1;
+                aoff[h][it] = (uint32_t)gm * (uint32_t)lda + c * 8;
+                int gn = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+                gn = gn < N ? gn : N - 1;
+                boff[h][it] = (uint32_t)gn * (uint32_t)ldw + c * 8;
+            }
+        }
+        const int nk = K >> 6;
+        koff = koff % nk;
+        auto kcol = [&](int kt) { int k = kt + koff; return (k >= nk ? k - nk : k) << 6; };
+        char* const wave_dst = smem + wid * 1024;               // wave-uniform; lane l lands at +16*l
+        auto issue_a = [&](int h, int kt, int buf) {
+            const uint16_t* base = Ag + kcol(kt);
+            char* dst = wave_dst + buf * BUF_BYTES + h * HALF_BYTES;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + aoff[h][0]), (lds_void_t*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + aoff[h][1]), (lds_void_t*)(dst + 8192), 16, 0, 0);
+        };
+        auto issue_b = [&](int g, int kt, int buf) {
+            const uint16_t* base = Wg + kcol(kt);
+            char* dst = wave_dst + buf * BUF_BYTES + (2 + g) * HALF_BYTES;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + boff[g][0]), (lds_void_t*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + boff[g][1]), (lds_void_t*)(dst + 8192), 16, 0, 0);
+        };
+
+        // fragment read offsets inside a half-tile
+        const int frow = lane & 15, fq = lane >> 4, sw = (lane >> 1) & 7;
+        const int fo0 = frow * 128 + (((0 + fq) ^ sw) << 4), fo1 = frow * 128 + (((4 + fq) ^ sw) << 4);
+        const int a_row = wr * 64 * 128, b_row = wc * 32 * 128;
+
+        vec af[4][2], wf0[2][2], wf1[2][2];
+        auto read_a = [&](const char* buf, int h) {
+            const char* p = buf + h * HALF_BYTES + a_row;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i][0] = *reinterpret_cast<const vec*>(p + i * 2048 + fo0);
+                af[i][1] = *reinterpret_cast<const vec*>(p + i * 2048 + fo1);
+            }
+        };
+        auto read_b = [&](const char* buf, int g, vec (&wf)[2][2]) {
+            const char* p = buf + (2 + g) * HALF_BYTES + b_row;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                wf[j][0] = *reinterpret_cast<const vec*>(p + j * 2048 + fo0);
+                wf[j][1] = *reinterpret_cast<const vec*>(p + j * 2048 + fo1);
+            }
+        };
+        auto quad = [&](int h, int g, const vec (&wf)[2][2]) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        acc[g * 2 + j][h * 4 + i] = Mfma<T>::mma(wf[j][ks], af[i][ks], acc[g * 2 + j][h * 4 + i]);
+            __builtin_amdgcn_s_setprio(0);
+        };
+
+        // prologue: k-tile 0 whole + the first three half-tiles of k-tile 1, in stream order
+        issue_b(0, 0, 0); issue_a(0, 0, 0); issue_b(1, 0, 0); issue_a(1, 0, 0);
+        if (nk > 1) {
+            issue_b(0, 1, 1); issue_a(0, 1, 1); issue_b(1, 1, 1);
+            wait_vmcnt<6>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        bar();
+#ifdef ARX_STAMP
+        g_stamp1 = __builtin_readcyclecounter();
+#endif
+        if (wr == 1) bar();                                     // group 1 runs one barrier interval late
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int b = kt & 1;
+            const char* cur = smem + b * BUF_BYTES;
+            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+            // ---- phase 1: quadrant (A-sub0, B-sub0)
+            read_b(cur, 0, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(cur, 0);
+            if (more1) issue_a(1, kt + 1, b ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the B-sub0 reads (issued first) are retired: B0 may be restaged in phase 2
+            bar();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            quad(0, 0, wf0);
+            bar();
+            // ---- phase 2: quadrant (A-sub0, B-sub1)
+            read_b(cur, 1, wf1);
+            if (more2) issue_b(0, kt + 2, b);
+            bar();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            quad(0, 1, wf1);
+            bar();
+            // ---- phase 3: quadrant (A-sub1, B-sub1)
+            read_a(cur, 1);
+            if (more2) issue_a(0, kt + 2, b);
+            bar();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            quad(1, 1, wf1);
+            bar();
+            // ---- phase 4: quadrant (A-sub1, B-sub0), fragments already in registers; the k-tile's one counted wait
+            if (more2) { issue_b(1, kt + 2, b); wait_vmcnt<6>(); }
+            else wait_vmcnt<0>();
+            bar();
+            quad(1, 0, wf0);
+            if (more1 || wr == 0) bar();                         // group 1 skips its very last barrier (counts stay equal)
+        }
+    }
+};
+
+template <int MODE, int KROT = 2>
+__global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                           const bf16_t* __restrict__ W, int64_t ldw,
+                                                           int M, int N, int K, int tiles_m, int tiles_n, EpiParams ep) {
+    using ML = Gemm8Phase<bf16_t, KROT>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tile_m = t / tiles_n, tile_n = t % tiles_n;
+    const int m0 = tile_m * 256, n0 = tile_n * 256;
+    f32x4 acc[ML::NI][ML::MI];
+#ifdef ARX_STAMP
+    const unsigned long long ts0 = __builtin_readcyclecounter();
+#endif
+#ifdef ARX_STAMP
+    unsigned long long ts1 = 0;
+    ML::run(A, lda, M, W, ldw, N, K, m0, n0, smem, acc, tile_n * KROT, ts1);
+#else
+    ML::run(A, lda, M, W, ldw, N, K, m0, n0, smem, acc, tile_n * KROT);
+#endif
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#ifdef ARX_STAMP
+    const unsigned long long ts2 = __builtin_readcyclecounter();
+#endif
+    epilogue_store_v2<MODE, ML::NI, ML::MI>(acc, ep, m0 + (wid >> 2) * 128, n0 + (wid & 3) * 64, lane, M, N);
+#ifdef ARX_STAMP
+    if (ep.stamps && (threadIdx.x == 0 || threadIdx.x == 256)) {
+        unsigned long long* o = ep.stamps + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 4;
+        o[0] = ts0; o[1] = ts2; o[2] = __builtin_readcyclecounter();
+        o[3] = ts1;
+    }
+#endif
+}

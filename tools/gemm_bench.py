@@ -70,6 +70,14 @@ for name, N, K, mode in shapes:
             for _ in range(2 if FAST else 5): run(v, A, W, b, R, C, mode)
             e1.record(); e1.synchronize()
             res[v]["t"].append(e0.elapsed_time(e1) / (2 if FAST else 5))
+    if os.environ.get("GEMM_BENCH_LIB") == "1":      # calibration only: the vendor GEMM on the same shape (no epilogue beyond bias)
+        tl = []
+        for rnd in range(5):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): torch.matmul(A, W.t(), out=C)
+            e1.record(); e1.synchronize(); tl.append(e0.elapsed_time(e1) / 5)
+        print(f"{name:6s} N={N:5d} K={K:5d} vendor matmul (no bias/act/resid): {np.median(tl):7.3f} ms  {flops/np.median(tl)/1e9:7.1f} TF")
     for v in variants:
         t = np.median(res[v]["t"]); tm = min(res[v]["t"])
         print(f"{name:6s} N={N:5d} K={K:5d} mode{mode} v{v}: {t:7.3f} ms (min {tm:.3f})  {flops/t/1e9:7.1f} TF   maxerr {res[v]['err']:.4f} nan={res[v]['nan']}")
