@@ -267,6 +267,18 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
             return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, false, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, false>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a7);
         }
     }
+    if (variant == 9 && wide && (K / 64) % 2 == 0 && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {   // persistent 4-phase schedule
+        static bool r9 = false;
+        static int n_cu = 0;
+        if (!n_cu) { int dev = 0; ARX_HIP_CHECK(hipGetDevice(&dev)); ARX_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)); }
+        auto kern = gemm_8phase_persistent_kernel<MODE>;
+        if (!r9) { ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8Phase<bf16_t, 2>::SMEM_BYTES)); r9 = true; }
+        const int tm = cdiv(M, 256), tn = cdiv(N, 256);
+        const int grid = tm * tn < n_cu ? tm * tn : n_cu;
+        kern<<<grid, 512, Gemm8Phase<bf16_t, 2>::SMEM_BYTES, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
+        ARX_HIP_CHECK(hipGetLastError());
+        return ARX_OK;
+    }
     if (variant == 8 && wide && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {      // 4-phase-per-k-tile schedule (gemm8.h)
         static bool r8 = false;
         return launch_gemm_kernel(gemm_8phase_kernel<MODE>, Gemm8Phase<bf16_t, 2>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &r8);

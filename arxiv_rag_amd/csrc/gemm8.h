@@ -21,6 +21,7 @@
 //        A0 (read in 1) restaged in 3, B1 (read in 2) in 4, A1 (read in 3) in phase 1 of the next k-tile.
 #pragma once
 #include "gemm.h"
+#include "epi3.h"
 
 #ifdef ARX_STAMP
 #define g_stamp1 stamp1_ref
@@ -28,7 +29,8 @@
 template <typename T, int KROT>
 struct Gemm8Phase {
     static constexpr int BM = 256, BN = 256, NT = 512, MI = 8, NI = 4;
-    static constexpr int HALF_BYTES = 128 * 128, BUF_BYTES = 4 * HALF_BYTES, SMEM_BYTES = 2 * BUF_BYTES;
+    static constexpr int HALF_BYTES = 128 * 128, BUF_BYTES = 4 * HALF_BYTES, STAGE_OFF = 2 * BUF_BYTES;
+    static constexpr int SMEM_BYTES = STAGE_OFF + 2 * EpiStage::BYTES;      // k-tile buffers + two epilogue-vector stages
     using vec = typename Mfma<T>::vec;
 
     static __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
 #ifdef ARX_STAMP
     const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
+    epi_stage_issue<MODE>(ep, m0, n0, smem + ML::STAGE_OFF, threadIdx.x >> 6, threadIdx.x & 63);   // oldest loads of the tile
 #ifdef ARX_STAMP
     unsigned long long ts1 = 0;
     ML::run(A, lda, M, W, ldw, N, K, m0, n0, smem, acc, tile_n * KROT, ts1);
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
 #ifdef ARX_STAMP
     const unsigned long long ts2 = __builtin_readcyclecounter();
 #endif
-    epilogue_store_v2<MODE, ML::NI, ML::MI>(acc, ep, m0 + (wid >> 2) * 128, n0 + (wid & 3) * 64, lane, M, N);
+    epilogue_store_v3<MODE>(acc, ep, m0, n0, wid >> 2, wid & 3, lane, M, smem + ML::STAGE_OFF);
 #ifdef ARX_STAMP
     if (ep.stamps && (threadIdx.x == 0 || threadIdx.x == 256)) {
         unsigned long long* o = ep.stamps + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 4;
@@ -201,4 +204,168 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
         o[3] = ts1;
     }
 #endif
+}
+
+// ---- persistent form: one block per CU walks tiles blockIdx.x, +gridDim.x, ... and the half-tile prefetch stream runs straight
+// through the tile boundary: the seven free issue slots of a tile's last two k-tiles carry the first seven half-tiles of the
+// next tile (exactly what the per-tile prologue above issues), so the first-load latency (~4 us) is paid once per CU instead of
+// once per tile, and the three half-tiles in flight land under the epilogue.  Needs an even number of k-tiles (buffer parity).
+template <int MODE, int KROT = 2>
+__global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                      const bf16_t* __restrict__ W, int64_t ldw,
+                                                                      int M, int N, int K, int tiles_m, int tiles_n, EpiParams ep) {
+    using ML = Gemm8Phase<bf16_t, KROT>;
+    using vec = typename ML::vec;
+    constexpr int HALF_BYTES = ML::HALF_BYTES, BUF_BYTES = ML::BUF_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 2, wc = wid & 3;
+    const uint16_t* Ag = reinterpret_cast<const uint16_t*>(A);
+    const uint16_t* Wg = reinterpret_cast<const uint16_t*>(W);
+    const int ntiles = tiles_m * tiles_n, stride = gridDim.x, nk = K >> 6;
+
+    auto tile_of = [&](int o, int& m0, int& n0, int& ko) {
+        const int t = xcd_remap(o, ntiles);
+        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+        m0 = tm * 256; n0 = tn * 256; ko = (tn * KROT) % nk;
+    };
+    auto kcol = [&](int kt, int ko) { int k = kt + ko; return (k >= nk ? k - nk : k) << 6; };
+
+    uint32_t aoff[2][2], boff[2][2];
+    auto set_aoff = [&](int h, int m0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int cid = it * 512 + tid, r = cid >> 3, c = (cid & 7) ^ ((r >> 1) & 7);
+            int gm = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
+            gm = gm < M ? gm : M - 1;
+            aoff[h][it] = (uint32_t)gm * (uint32_t)lda + c * 8;
+        }
+    };
+    auto set_boff = [&](int g, int n0) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int cid = it * 512 + tid, r = cid >> 3, c = (cid & 7) ^ ((r >> 1) & 7);
+            int gn = n0 + (r >> 5) * 64 + g * 32 + (r & 31);
+            gn = gn < N ? gn : N - 1;
+            boff[g][it] = (uint32_t)gn * (uint32_t)ldw + c * 8;
+        }
+    };
+    char* const wave_dst = smem + wid * 1024;
+    auto issue_a = [&](int h, int kc, int buf) {
+        const uint16_t* base = Ag + kc;
+        char* dst = wave_dst + buf * BUF_BYTES + h * HALF_BYTES;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + aoff[h][0]), (lds_void_t*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + aoff[h][1]), (lds_void_t*)(dst + 8192), 16, 0, 0);
+    };
+    auto issue_b = [&](int g, int kc, int buf) {
+        const uint16_t* base = Wg + kc;
+        char* dst = wave_dst + buf * BUF_BYTES + (2 + g) * HALF_BYTES;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + boff[g][0]), (lds_void_t*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + boff[g][1]), (lds_void_t*)(dst + 8192), 16, 0, 0);
+    };
+    const int frow = lane & 15, fq = lane >> 4, sw = (lane >> 1) & 7;
+    const int fo0 = frow * 128 + (((0 + fq) ^ sw) << 4), fo1 = frow * 128 + (((4 + fq) ^ sw) << 4);
+    const int a_row = wr * 64 * 128, b_row = wc * 32 * 128;
+
+    f32x4 acc[4][8];
+    vec af[4][2], wf0[2][2], wf1[2][2];
+    auto read_a = [&](const char* buf, int h) {
+        const char* p = buf + h * HALF_BYTES + a_row;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i][0] = *reinterpret_cast<const vec*>(p + i * 2048 + fo0);
+            af[i][1] = *reinterpret_cast<const vec*>(p + i * 2048 + fo1);
+        }
+    };
+    auto read_b = [&](const char* buf, int g, vec (&wf)[2][2]) {
+        const char* p = buf + (2 + g) * HALF_BYTES + b_row;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            wf[j][0] = *reinterpret_cast<const vec*>(p + j * 2048 + fo0);
+            wf[j][1] = *reinterpret_cast<const vec*>(p + j * 2048 + fo1);
+        }
+    };
+    auto quad = [&](int h, int g, const vec (&wf)[2][2]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[g * 2 + j][h * 4 + i] = Mfma<bf16_t>::mma(wf[j][ks], af[i][ks], acc[g * 2 + j][h * 4 + i]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    int orig = blockIdx.x;
+    if (orig >= ntiles) return;
+    int m0, n0, ko;
+    tile_of(orig, m0, n0, ko);
+    set_aoff(0, m0); set_aoff(1, m0); set_boff(0, n0); set_boff(1, n0);
+    issue_b(0, kcol(0, ko), 0); issue_a(0, kcol(0, ko), 0); issue_b(1, kcol(0, ko), 0); issue_a(1, kcol(0, ko), 0);
+    issue_b(0, kcol(1, ko), 1); issue_a(0, kcol(1, ko), 1); issue_b(1, kcol(1, ko), 1);
+    wait_vmcnt<6>();
+    ML::bar();
+    if (wr == 1) ML::bar();
+
+    for (;;) {
+        const int onext = orig + stride;
+        const bool has_next = onext < ntiles;
+        int m0n = 0, n0n = 0, kon = 0;
+        if (has_next) tile_of(onext, m0n, n0n, kon);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nk; ++kt) {
+            const int b = kt & 1;
+            const char* cur = smem + b * BUF_BYTES;
+            const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+            const bool go1 = more1 || has_next, go2 = more2 || has_next;
+            const int kc1 = more1 ? kcol(kt + 1, ko) : kcol(0, kon);
+            const int kc2 = more2 ? kcol(kt + 2, ko) : kcol(kt + 2 - nk, kon);
+            // ---- phase 1
+            read_b(cur, 0, wf0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(cur, 0);
+            if (!more1 && has_next) {                            // the stream's A1 pieces now come from the next tile
+                asm volatile("" : "+s"(m0n));                    // (computed here, not hoisted: VGPRs are scarce in the loop)
+                set_aoff(1, m0n);
+            }
+            if (go1) issue_a(1, kc1, b ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            ML::bar();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            quad(0, 0, wf0);
+            ML::bar();
+            // ---- phase 2
+            read_b(cur, 1, wf1);
+            if (kt == nk - 2 && has_next) {
+                asm volatile("" : "+s"(m0n), "+s"(n0n));
+                set_boff(0, n0n); set_aoff(0, m0n); set_boff(1, n0n);
+            }
+            if (go2) issue_b(0, kc2, b);
+            ML::bar();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            quad(0, 1, wf1);
+            ML::bar();
+            // ---- phase 3
+            read_a(cur, 1);
+            if (go2) issue_a(0, kc2, b);
+            ML::bar();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            quad(1, 1, wf1);
+            ML::bar();
+            // ---- phase 4
+            if (go2) { issue_b(1, kc2, b); wait_vmcnt<6>(); }
+            else wait_vmcnt<0>();
+            ML::bar();
+            quad(1, 0, wf0);
+            if (go1 || wr == 0) ML::bar();
+        }
+        epilogue_store_v2<MODE, 4, 8>(acc, ep, m0 + wr * 128, n0 + wc * 64, lane, M, N);
+        if (!has_next) break;
+        orig = onext; m0 = m0n; n0 = n0n; ko = kon;
+    }
 }
