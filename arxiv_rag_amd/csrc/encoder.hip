@@ -45,7 +45,7 @@ struct arx_encoder {
     std::vector<float*> s_qkv, c_qkv, s_fc1, c_fc1;
     float *st1_sum = nullptr, *st1_sq = nullptr, *st2_sum = nullptr, *st2_sq = nullptr;   // row mean / rstd of y1 / y2
     float *part_s = nullptr, *part_q = nullptr;                                              // [H/64][tok_pad] partial slabs
-    int variant = 8;
+    int variant = 89;
     int attn_variant = 1;
 };
 
@@ -111,7 +111,7 @@ extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_e
     h->max_seqs = max_seqs;
     h->tok_pad = (int)round_up64(max_tokens, 256);
     const char* e = getenv("ARX_GEMM_VARIANT");
-    h->variant = e ? atoi(e) : 8;
+    h->variant = e ? atoi(e) : 89;
     const char* av = getenv("ARX_ATTN_VARIANT");
     h->attn_variant = av ? atoi(av) : 1;
     const char* g = getenv("ARX_GEMM_GLDS");          // legacy switch: 0 = register-staged reference loop
@@ -267,6 +267,9 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
             return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, false, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, false>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a7);
         }
     }
+    // 89 = DEFAULT: persistent kernel where the epilogue has no residual stream (QKV, FFN-1: +1..4 % measured in situ), per-tile
+    // kernel for the residual/statistics epilogues (their persistent form spills and is 10-20 % slower)
+    if (variant == 89) variant = (MODE == EPI_BIAS || MODE == EPI_BIAS_GELU || MODE == EPI_LN_BIAS || MODE == EPI_LN_BIAS_GELU) ? 9 : 8;
     if (variant == 9 && wide && (K / 64) % 2 == 0 && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {   // persistent 4-phase schedule
         static bool r9 = false;
         static int n_cu = 0;
@@ -352,6 +355,12 @@ extern "C" int32_t arx_gemm_bf16(const void* A, const void* W, const float* bias
                     loop[g] += (double)(o[1] - o[3]); epi[g] += (double)(o[2] - o[1]); pro[g] += (double)(o[3] - o[0]);
                     tmin = o[0] < tmin ? o[0] : tmin; tmax = o[2] > tmax ? o[2] : tmax;
                 }
+            if (variant == 9) {   // persistent: tile t+256 follows tile t on the same CU -> gap between epilogue end and next loop start, tile period
+                double gap = 0, period = 0; int n = 0;
+                for (int t = 0; t + 256 < tiles; ++t) { const unsigned long long* a = &hbuf[(size_t)t * 8]; const unsigned long long* b = &hbuf[(size_t)(t + 256) * 8];
+                    gap += (double)(b[0] - a[2]); period += (double)(b[0] - a[0]); ++n; }
+                if (n) fprintf(stderr, "[stamp] persistent: g0 tile period %.0f clk, epilogue-end -> next loop start %.0f clk\n", period / n, gap / n);
+            }
             fprintf(stderr, "[stamp] M=%d N=%d K=%d mode=%d tiles=%d: prologue %.0f / %.0f, loop g0 %.0f g1 %.0f clk, epilogue g0 %.0f g1 %.0f clk, span %.0f clk, tiles/CU %.1f\n",
                     M, N, K, mode, tiles, pro[0] / tiles, pro[1] / tiles, loop[0] / tiles, loop[1] / tiles, epi[0] / tiles, epi[1] / tiles, (double)(tmax - tmin), tiles / 256.0);
             return rc;

@@ -6,9 +6,9 @@
 // Epilogue v3 (for the 256-wide kernels above): every per-column / per-row VECTOR the epilogue needs (bias, s_n, the
 // residual LayerNorm's gamma/beta; row mean / rstd of the A operand and of the residual) is staged in LDS by ONE
 // global_load_lds per wave at the very start of the tile (8 x 1 KB behind the k-tile buffers), so the epilogue issues no
-// small global loads at all; the residual vectors of BOTH column pairs are requested before anything is consumed (one exposed
+// small global loads at all; the residual vectors ride a rolling window eight (column pair, row block) steps ahead of their use (one exposed
 // latency instead of two, and no store drain in between: a vmcnt wait for the second pair's loads used to wait for the first
-// pair's stores as well).  Same arithmetic and output bits as epilogue_store_v2 (asserted by the variant tests).
+// pair's stores as well).  Same arithmetic as epilogue_store_v2.
 struct EpiStage {
     enum { BIAS = 0, SVEC = 1, RGAMMA = 2, RBETA = 3, AMEAN = 4, ARSTD = 5, RMEAN = 6, RRSTD = 7, BYTES = 8 * 1024 };
 };
@@ -17,26 +17,30 @@ template <int MODE>
 __device__ __forceinline__ void epi_stage_issue(const EpiParams& p, int m0, int n0, char* stage, int wid, int lane) {
     constexpr bool LN_IN = (MODE == EPI_LN_BIAS || MODE == EPI_LN_BIAS_GELU);
     constexpr bool LNR = (MODE == EPI_LNRESID_STATS);
+    const int w = wid;                                           // wave-uniform (readfirstlane'd by the caller): scalar select and branch
     const float* src = nullptr;
-    if (wid == EpiStage::BIAS) src = p.bias + n0;
+    if (w == EpiStage::BIAS) src = p.bias + n0;
     if constexpr (LN_IN) {
-        if (wid == EpiStage::SVEC) src = p.s_vec + n0;
-        if (wid == EpiStage::AMEAN) src = p.a_sum + m0;
-        if (wid == EpiStage::ARSTD) src = p.a_sq + m0;
+        if (w == EpiStage::SVEC) src = p.s_vec + n0;
+        if (w == EpiStage::AMEAN) src = p.a_sum + m0;
+        if (w == EpiStage::ARSTD) src = p.a_sq + m0;
     }
     if constexpr (LNR) {
-        if (wid == EpiStage::RGAMMA) src = p.r_gamma + n0;
-        if (wid == EpiStage::RBETA) src = p.r_beta + n0;
-        if (wid == EpiStage::RMEAN) src = p.r_sum + m0;
-        if (wid == EpiStage::RRSTD) src = p.r_sq + m0;
+        if (w == EpiStage::RGAMMA) src = p.r_gamma + n0;
+        if (w == EpiStage::RBETA) src = p.r_beta + n0;
+        if (w == EpiStage::RMEAN) src = p.r_sum + m0;
+        if (w == EpiStage::RRSTD) src = p.r_sq + m0;
     }
-    if (src) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + lane * 4), (lds_void_t*)(stage + wid * 1024), 16, 0, 0);
+    // lane id recomputed by v_mbcnt (two VALU ops) rather than kept live or spilled across the k-loop
+    const unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    (void)lane;
+    if (src) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + l * 4), (lds_void_t*)(stage + w * 1024), 16, 0, 0);
 }
 
 template <int MODE, bool CHECK>
 __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8], const EpiParams& p, int m0, int n0, int wr, int wc,
                                                        int lane, int M, const char* stage) {
-    constexpr int NI = 4, MI = 8;
+    constexpr int NI = 4, MI = 8, NS = (NI / 2) * MI, DEPTH = 8;      // NS (column pair, row block) steps; residual loads DEPTH steps ahead
     constexpr bool LN_IN = (MODE == EPI_LN_BIAS || MODE == EPI_LN_BIAS_GELU);
     constexpr bool STATS = (MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS);
     constexpr bool RESID = (MODE == EPI_BIAS_RESID || STATS);
@@ -44,57 +48,50 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
     const int mq = lane & 15, q = lane >> 4, odd = q & 1;
     const int m_base = m0 + wr * 128, n_base = n0 + wc * 64;
     const float* sf = reinterpret_cast<const float*>(stage);
-    uint32_t orow[MI], rrow[MI];
-    bool rok[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        int m = m_base + i * 16 + mq;
-        rok[i] = !CHECK || m < M;
-        if (CHECK) m = m < M ? m : M - 1;
-        orow[i] = (uint32_t)m * (uint32_t)p.ldc;
-        rrow[i] = (uint32_t)m * (uint32_t)p.ldr;
-    }
-    // residual vectors of both column pairs, requested up front
-    u32x4 rres[NI / 2][MI];
+    // row offsets are rebuilt per step from one base (block-uniform strides): the epilogue must stay well under 256 VGPRs or
+    // the persistent kernel's loop-carried state gets spilled INTO the k-loop
+    auto row_of = [&](int i) { int m = m_base + i * 16 + mq; if (CHECK) m = m < M ? m : M - 1; return m; };
+    auto row_ok = [&](int i) { return !CHECK || (m_base + i * 16 + mq) < M; };
+    auto col_of = [&](int jp) { return wc * 64 + (2 * jp + odd) * 16 + (q >> 1) * 8; };     // column inside the block tile
+    u32x4 rres[DEPTH];
+    auto res_load = [&](int st) {
+        const int i = st / (NI / 2), jp = st % (NI / 2);
+        if (row_ok(i)) rres[st % DEPTH] = *reinterpret_cast<const u32x4*>(p.resid + (uint32_t)row_of(i) * (uint32_t)p.ldr + n0 + col_of(jp));
+    };
     if constexpr (RESID) {
 #pragma unroll
-        for (int jp = 0; jp < NI / 2; ++jp) {
-            const int n = n_base + (2 * jp + odd) * 16 + (q >> 1) * 8;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                if (rok[i]) rres[jp][i] = *reinterpret_cast<const u32x4*>(p.resid + rrow[i] + n);
-        }
+        for (int st = 0; st < DEPTH; ++st) res_load(st);
     }
-    float st_s[MI], st_q[MI];
+    // row-block outer, column-pair inner: a row block's statistics close after two steps (2 live registers, not 16), and the
+    // column vectors are simply re-read from the LDS stage each step (three to six ds_read_b128)
+    float st_s = 0.f, st_q = 0.f;
+    f32x2 bb[4], ss[4], gg[4], ee[4];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
-#pragma unroll
-    for (int jp = 0; jp < NI / 2; ++jp) {
-        const int cb = wc * 64 + (2 * jp + odd) * 16 + (q >> 1) * 8;          // column inside the block tile
-        const int n = n0 + cb;
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(sf + EpiStage::BIAS * 256 + cb), b1 = *reinterpret_cast<const f32x4*>(sf + EpiStage::BIAS * 256 + cb + 4);
-        const f32x2 bb[4] = {f32x2{b0[0], b0[1]}, f32x2{b0[2], b0[3]}, f32x2{b1[0], b1[1]}, f32x2{b1[2], b1[3]}};
-        f32x2 ss[4], gg[4], ee[4];
-        if constexpr (LN_IN) {
-            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sf + EpiStage::SVEC * 256 + cb), s1 = *reinterpret_cast<const f32x4*>(sf + EpiStage::SVEC * 256 + cb + 4);
-            ss[0] = f32x2{s0[0], s0[1]}; ss[1] = f32x2{s0[2], s0[3]}; ss[2] = f32x2{s1[0], s1[1]}; ss[3] = f32x2{s1[2], s1[3]};
-        }
-        if constexpr (LNR) {
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(sf + EpiStage::RGAMMA * 256 + cb), g1 = *reinterpret_cast<const f32x4*>(sf + EpiStage::RGAMMA * 256 + cb + 4);
-            const f32x4 e0 = *reinterpret_cast<const f32x4*>(sf + EpiStage::RBETA * 256 + cb), e1 = *reinterpret_cast<const f32x4*>(sf + EpiStage::RBETA * 256 + cb + 4);
-            gg[0] = f32x2{g0[0], g0[1]}; gg[1] = f32x2{g0[2], g0[3]}; gg[2] = f32x2{g1[0], g1[1]}; gg[3] = f32x2{g1[2], g1[3]};
-            ee[0] = f32x2{e0[0], e0[1]}; ee[1] = f32x2{e0[2], e0[3]}; ee[2] = f32x2{e1[0], e1[1]}; ee[3] = f32x2{e1[2], e1[3]};
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            f32x4 lo, hi;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * jp][i][r]),
-                                                                 __float_as_uint(acc[2 * jp + 1][i][r]), false, false);
-                lo[r] = __uint_as_float(sw[0]); hi[r] = __uint_as_float(sw[1]);
+    for (int st = 0; st < NS; ++st) {
+        const int i = st / (NI / 2), jp = st % (NI / 2);
+        const int cb = col_of(jp);
+        {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(sf + EpiStage::BIAS * 256 + cb), b1 = *reinterpret_cast<const f32x4*>(sf + EpiStage::BIAS * 256 + cb + 4);
+            bb[0] = f32x2{b0[0], b0[1]}; bb[1] = f32x2{b0[2], b0[3]}; bb[2] = f32x2{b1[0], b1[1]}; bb[3] = f32x2{b1[2], b1[3]};
+            if constexpr (LN_IN) {
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sf + EpiStage::SVEC * 256 + cb), s1 = *reinterpret_cast<const f32x4*>(sf + EpiStage::SVEC * 256 + cb + 4);
+                ss[0] = f32x2{s0[0], s0[1]}; ss[1] = f32x2{s0[2], s0[3]}; ss[2] = f32x2{s1[0], s1[1]}; ss[3] = f32x2{s1[2], s1[3]};
             }
-            if (CHECK && !rok[i]) continue;
+            if constexpr (LNR) {
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(sf + EpiStage::RGAMMA * 256 + cb), g1 = *reinterpret_cast<const f32x4*>(sf + EpiStage::RGAMMA * 256 + cb + 4);
+                const f32x4 e0 = *reinterpret_cast<const f32x4*>(sf + EpiStage::RBETA * 256 + cb), e1 = *reinterpret_cast<const f32x4*>(sf + EpiStage::RBETA * 256 + cb + 4);
+                gg[0] = f32x2{g0[0], g0[1]}; gg[1] = f32x2{g0[2], g0[3]}; gg[2] = f32x2{g1[0], g1[1]}; gg[3] = f32x2{g1[2], g1[3]};
+                ee[0] = f32x2{e0[0], e0[1]}; ee[1] = f32x2{e0[2], e0[3]}; ee[2] = f32x2{e1[0], e1[1]}; ee[3] = f32x2{e1[2], e1[3]};
+            }
+        }
+        f32x4 lo, hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * jp][i][r]),
+                                                             __float_as_uint(acc[2 * jp + 1][i][r]), false, false);
+            lo[r] = __uint_as_float(sw[0]); hi[r] = __uint_as_float(sw[1]);
+        }
+        if (row_ok(i)) {
             const int rb = wr * 128 + i * 16 + mq;                            // row inside the block tile
             f32x2 vv[4] = {f32x2{lo[0], lo[1]}, f32x2{lo[2], lo[3]}, f32x2{hi[0], hi[1]}, f32x2{hi[2], hi[3]}};
             if constexpr (LN_IN) {
@@ -111,43 +108,46 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
                 for (int pi = 0; pi < 4; ++pi) vv[pi] = gelu_poly_pk(vv[pi]);
             }
             if constexpr (RESID) {
-                const u32x4 rr = rres[jp][i];
+                const u32x4 rr = rres[st % DEPTH];
+                float rm = 0.f, rsd = 1.f;
+                if constexpr (LNR) { rm = sf[EpiStage::RMEAN * 256 + rb]; rsd = sf[EpiStage::RRSTD * 256 + rb]; }
 #pragma unroll
                 for (int pi = 0; pi < 4; ++pi) {
                     float r0, r1;
                     unpack_bf16x2(rr[pi], r0, r1);
                     f32x2 ra = f32x2{r0, r1};
-                    if constexpr (LNR) {
-                        const float rm = sf[EpiStage::RMEAN * 256 + rb], rsd = sf[EpiStage::RRSTD * 256 + rb];
-                        ra = ((ra - f32x2{rm, rm}) * f32x2{rsd, rsd}) * gg[pi] + ee[pi];
-                    }
+                    if constexpr (LNR) ra = ((ra - f32x2{rm, rm}) * f32x2{rsd, rsd}) * gg[pi] + ee[pi];
                     vv[pi] = vv[pi] + ra;
                 }
             }
             u32x4 o;
 #pragma unroll
             for (int pi = 0; pi < 4; ++pi) o[pi] = pack_bf16x2(vv[pi].x, vv[pi].y);
-            *reinterpret_cast<u32x4*>(p.out + orow[i] + n) = o;
+            *reinterpret_cast<u32x4*>(p.out + (uint32_t)row_of(i) * (uint32_t)p.ldc + n0 + cb) = o;
             if constexpr (STATS) {
+                // statistics of the bf16-ROUNDED values (what the consumers will read back)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float x0, x1;
                     unpack_bf16x2(o[r], x0, x1);
-                    st_s[i] += x0 + x1;
-                    st_q[i] = fmaf(x0, x0, fmaf(x1, x1, st_q[i]));
+                    st_s += x0 + x1;
+                    st_q = fmaf(x0, x0, fmaf(x1, x1, st_q));
                 }
             }
         }
-    }
-    if constexpr (STATS) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            float a = st_s[i], b = st_q[i];
-            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-            b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-            const int m = m_base + i * 16 + mq;
-            const int64_t part = n_base >> 6;
-            if (q == 0 && m < M) { p.o_sum[part * p.o_ld + m] = a; p.o_sq[part * p.o_ld + m] = b; }
+        if constexpr (RESID) {
+            if (st + DEPTH < NS) res_load(st + DEPTH);           // refill the slot just consumed
+        }
+        if constexpr (STATS) {
+            if (jp == NI / 2 - 1) {                              // row block complete: this wave's 64-column partial
+                float a = st_s, b = st_q;
+                a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+                const int m = m_base + i * 16 + mq;
+                const int64_t part = n_base >> 6;
+                if (q == 0 && m < M) { p.o_sum[part * p.o_ld + m] = a; p.o_sq[part * p.o_ld + m] = b; }
+                st_s = 0.f; st_q = 0.f;
+            }
         }
     }
 }

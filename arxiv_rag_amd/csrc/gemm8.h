@@ -45,7 +45,7 @@ struct Gemm8Phase {
                                                , unsigned long long& stamp1_ref
 #endif
                                                ) {
-        const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+        const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPRs
         const int wr = wid >> 2, wc = wid & 3;
         const uint16_t* Ag = reinterpret_cast<const uint16_t*>(A);
         const uint16_t* Wg = reinterpret_cast<const uint16_t*>(W);
@@ -185,14 +185,14 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
 #ifdef ARX_STAMP
     const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
-    epi_stage_issue<MODE>(ep, m0, n0, smem + ML::STAGE_OFF, threadIdx.x >> 6, threadIdx.x & 63);   // oldest loads of the tile
+    epi_stage_issue<MODE>(ep, m0, n0, smem + ML::STAGE_OFF, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);   // oldest loads of the tile
 #ifdef ARX_STAMP
     unsigned long long ts1 = 0;
     ML::run(A, lda, M, W, ldw, N, K, m0, n0, smem, acc, tile_n * KROT, ts1);
 #else
     ML::run(A, lda, M, W, ldw, N, K, m0, n0, smem, acc, tile_n * KROT);
 #endif
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #ifdef ARX_STAMP
     const unsigned long long ts2 = __builtin_readcyclecounter();
 #endif
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
     using vec = typename ML::vec;
     constexpr int HALF_BYTES = ML::HALF_BYTES, BUF_BYTES = ML::BUF_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: SGPRs
     const int wr = wid >> 2, wc = wid & 3;
     const uint16_t* Ag = reinterpret_cast<const uint16_t*>(A);
     const uint16_t* Wg = reinterpret_cast<const uint16_t*>(W);
@@ -302,6 +302,8 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
     int m0, n0, ko;
     tile_of(orig, m0, n0, ko);
     set_aoff(0, m0); set_aoff(1, m0); set_boff(0, n0); set_boff(1, n0);
+    int sbuf = 0;                                                // epilogue-vector stage of the current tile (alternates)
+    epi_stage_issue<MODE>(ep, m0, n0, smem + ML::STAGE_OFF, wid, lane);
     issue_b(0, kcol(0, ko), 0); issue_a(0, kcol(0, ko), 0); issue_b(1, kcol(0, ko), 0); issue_a(1, kcol(0, ko), 0);
     issue_b(0, kcol(1, ko), 1); issue_a(0, kcol(1, ko), 1); issue_b(1, kcol(1, ko), 1);
     wait_vmcnt<6>();
@@ -313,10 +315,16 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
         const bool has_next = onext < ntiles;
         int m0n = 0, n0n = 0, kon = 0;
         if (has_next) tile_of(onext, m0n, n0n, kon);
+        // interior -> interior tile steps move every source offset by a block-uniform amount
+        const bool edge = (m0 + 256 > M) || (m0n + 256 > M);
+        const uint32_t d_a = (uint32_t)(m0n - m0) * (uint32_t)lda, d_b = (uint32_t)(n0n - n0) * (uint32_t)ldw;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef ARX_STAMP
+        const unsigned long long pts0 = __builtin_readcyclecounter();
+#endif
 
         for (int kt = 0; kt < nk; ++kt) {
             const int b = kt & 1;
@@ -329,9 +337,11 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             read_b(cur, 0, wf0);
             __builtin_amdgcn_sched_barrier(0);
             read_a(cur, 0);
+            if (kt == nk - 1 && has_next)                        // next tile's epilogue vectors: ahead of (older than) its A1 pieces
+                epi_stage_issue<MODE>(ep, m0n, n0n, smem + ML::STAGE_OFF + (sbuf ^ 1) * EpiStage::BYTES, wid, lane);
             if (!more1 && has_next) {                            // the stream's A1 pieces now come from the next tile
-                asm volatile("" : "+s"(m0n));                    // (computed here, not hoisted: VGPRs are scarce in the loop)
-                set_aoff(1, m0n);
+                if (edge) { asm volatile("" : "+s"(m0n)); set_aoff(1, m0n); }      // clamped rows: recompute (last tile row only)
+                else { aoff[1][0] += d_a; aoff[1][1] += d_a; }
             }
             if (go1) issue_a(1, kc1, b ^ 1);
             asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -342,8 +352,9 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             // ---- phase 2
             read_b(cur, 1, wf1);
             if (kt == nk - 2 && has_next) {
-                asm volatile("" : "+s"(m0n), "+s"(n0n));
-                set_boff(0, n0n); set_aoff(0, m0n); set_boff(1, n0n);
+                boff[0][0] += d_b; boff[0][1] += d_b; boff[1][0] += d_b; boff[1][1] += d_b;   // N % 256 == 0: never clamped
+                if (edge) { asm volatile("" : "+s"(m0n)); set_aoff(0, m0n); }
+                else { aoff[0][0] += d_a; aoff[0][1] += d_a; }
             }
             if (go2) issue_b(0, kc2, b);
             ML::bar();
@@ -364,8 +375,17 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             quad(1, 0, wf0);
             if (go1 || wr == 0) ML::bar();
         }
-        epilogue_store_v2<MODE, 4, 8>(acc, ep, m0 + wr * 128, n0 + wc * 64, lane, M, N);
+#ifdef ARX_STAMP
+        const unsigned long long pts1 = __builtin_readcyclecounter();
+#endif
+        epilogue_store_v3<MODE>(acc, ep, m0, n0, wr, wc, lane, M, smem + ML::STAGE_OFF + sbuf * EpiStage::BYTES);
+#ifdef ARX_STAMP
+        if (ep.stamps && (tid == 0 || tid == 256)) {
+            unsigned long long* o = ep.stamps + ((size_t)orig * 2 + (tid >> 8)) * 4;
+            o[0] = pts0; o[1] = pts1; o[2] = __builtin_readcyclecounter(); o[3] = pts0;
+        }
+#endif
         if (!has_next) break;
-        orig = onext; m0 = m0n; n0 = n0n; ko = kon;
+        orig = onext; m0 = m0n; n0 = n0n; ko = kon; sbuf ^= 1;
     }
 }

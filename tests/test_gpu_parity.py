@@ -326,7 +326,7 @@ def test_collection_query_shape_and_ranking(hip, tmp_path):
         assert res["documents"][qi][0] == f"text {ri[qi][0]}" and res["metadatas"][qi][0]["paper_id"] == f"p{ri[qi][0] % 7}"
 
 
-@pytest.mark.parametrize("variant", [8, 13, 33, 34, 15, 1, 3, 2, 0, 4])
+@pytest.mark.parametrize("variant", [89, 9, 8, 13, 33, 34, 15, 1, 3, 2, 0, 4])
 def test_linear_layer_variants_vs_fp32(hip, variant):
     """arx_gemm_bf16 (the linear layer of the path) against an fp32 matmul on the same bf16-rounded operands:
     every main-loop schedule kept in the tree, every epilogue mode it supports, ragged M/N (masked edge tiles)."""
@@ -351,7 +351,34 @@ def test_linear_layer_variants_vs_fp32(hip, variant):
             assert err < 0.02 * max(1.0, want.abs().max().item()), (variant, M, N, K, mode, err)
 
 
-@pytest.mark.parametrize("env", [{"ARX_LN_FOLD": "0"}, {"ARX_ATTN_VARIANT": "0"}, {"ARX_GEMM_VARIANT": "3"}])
+def test_persistent_gemm_bitwise_equals_per_tile_kernel(hip):
+    """The persistent form of the 4-phase GEMM (prefetch stream running through tile boundaries, several tiles per block,
+    a ragged last tile row) must reproduce the per-tile kernel bit for bit: same k order, same epilogue."""
+    lib = hip.load()
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    st = torch.cuda.current_stream().cuda_stream
+    for (M, N, K) in ((70001, 768, 768), (33000, 2304, 768), (40000, 768, 3072), (300, 512, 128)):
+        A = torch.randn((M, K), device="cuda", generator=g).to(torch.bfloat16)
+        W = (torch.randn((N, K), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn((N,), device="cuda", generator=g)
+        R = torch.randn((M, N), device="cuda", generator=g).to(torch.bfloat16)
+        for mode in (0, 1, 2):
+            outs = []
+            for variant in (8, 9, 9):
+                out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+                hip.check(lib.arx_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, mode,
+                                            variant, st), "arx_gemm_bf16")
+                outs.append(out)
+            assert not torch.isnan(outs[0].float()).any()
+            assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (M, N, K, mode)
+            assert torch.equal(outs[1].view(torch.int16), outs[2].view(torch.int16)), (M, N, K, mode)
+        rows = torch.randint(0, M, (512,), device="cuda", generator=g)
+        want = A[rows].float() @ W.float().T + b + R[rows].float()
+        assert (outs[2][rows].float() - want).abs().max().item() < 0.02 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("env", [{"ARX_LN_FOLD": "0"}, {"ARX_ATTN_VARIANT": "0"}, {"ARX_GEMM_VARIANT": "3"},
+                                 {"ARX_GEMM_VARIANT": "13"}, {"ARX_GEMM_VARIANT": "8"}, {"ARX_GEMM_VARIANT": "9"}])
 def test_alternative_schedules_agree(hip, golden_dir, env, monkeypatch):
     """The A/B schedules kept in the tree (explicit LayerNorm kernels, first attention kernel, ring GEMM) against the same
     golden vectors as the default path, and against the default path itself."""
