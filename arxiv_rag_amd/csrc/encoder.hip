@@ -277,14 +277,20 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
         auto kern = gemm_8phase_persistent_kernel<MODE>;
         if (!r9) { ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8Phase<bf16_t, 2>::SMEM_BYTES)); r9 = true; }
         const int tm = cdiv(M, 256), tn = cdiv(N, 256);
-        const int grid = tm * tn < n_cu ? tm * tn : n_cu;
+        int grid = TileWalk::grid(tm, tn) < n_cu ? TileWalk::grid(tm, tn) : n_cu;
+        grid = grid / 8 * 8 > 0 ? grid / 8 * 8 : grid;            // a multiple of 8: a block keeps its XCD across tiles
         kern<<<grid, 512, Gemm8Phase<bf16_t, 2>::SMEM_BYTES, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
         ARX_HIP_CHECK(hipGetLastError());
         return ARX_OK;
     }
     if (variant == 8 && wide && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {      // 4-phase-per-k-tile schedule (gemm8.h)
         static bool r8 = false;
-        return launch_gemm_kernel(gemm_8phase_kernel<MODE>, Gemm8Phase<bf16_t, 2>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &r8);
+        auto kern = gemm_8phase_kernel<MODE>;
+        if (!r8) { ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8Phase<bf16_t, 2>::SMEM_BYTES)); r8 = true; }
+        const int tm = cdiv(M, 256), tn = cdiv(N, 256);
+        kern<<<TileWalk::grid(tm, tn), 512, Gemm8Phase<bf16_t, 2>::SMEM_BYTES, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
+        ARX_HIP_CHECK(hipGetLastError());
+        return ARX_OK;
     }
     if (variant == 34 && wide) {      // ping-pong: the two waves of a SIMD half a k-step apart
         static bool r2 = false;

@@ -26,6 +26,39 @@
 #ifdef ARX_STAMP
 #define g_stamp1 stamp1_ref
 #endif
+
+// Tile walk of the 256-wide kernels.  Block id -> (XCD = id % 8, position L = id / 8 inside that XCD's share).  An XCD owns a
+// contiguous range of m-panels (all their n-tiles) and walks it BAND by band: a band is `bw` adjacent n-tiles chosen so that the
+// band's slice of W (bw x 256 x K bf16) stays resident in the XCD's 4-MB L2 while the A panels stream through once per band;
+// inside a band the order is n-fastest, so the CUs of an XCD share both the A panel and the W slices they are reading.
+// Without bands (bw = tiles_n) FFN-1's 4.7-MB W and the A stream evict each other: 2.9 GB of L2 fills per launch against
+// 0.41 GB of operands (rocprofv3 FETCH_SIZE); with two bands of six the A operand is filled twice and W about once.
+struct TileWalk {
+    int tiles_m, tiles_n, bw;
+    __device__ __forceinline__ TileWalk(int tm, int tn, int K) : tiles_m(tm), tiles_n(tn) {
+        const int w_tile = 512 * K;                               // bytes of one n-tile's W slice
+        const int total = tn * w_tile;
+        bw = tn;
+        if (total > (5 << 19) && K <= 1024) {                     // > 2.5 MB and a small A operand: band it (~2.4 MB per band)
+            const int nb = (total + (12 << 18) / 5 * 4 - 1) / ((12 << 18) / 5 * 4);
+            bw = (tn + nb - 1) / nb;
+        }
+    }
+    // grid size that covers every XCD's share
+    static int grid(int tm, int tn) { return 8 * ((tm + 7) / 8) * tn; }
+    __device__ __forceinline__ bool coords(int id, int& tile_m, int& tile_n) const {
+        const int x = id & 7;
+        int L = id >> 3;
+        const int pq = tiles_m >> 3, pr = tiles_m & 7;
+        const int panels = pq + (x < pr ? 1 : 0), m_lo = x * pq + (x < pr ? x : pr);
+        if (L >= panels * tiles_n) return false;
+        int b = 0, w = bw < tiles_n ? bw : tiles_n;
+        while (L >= panels * w) { L -= panels * w; ++b; w = tiles_n - b * bw; w = w < bw ? w : bw; }
+        const int q = L / w;
+        tile_m = m_lo + q; tile_n = b * bw + (L - q * w);
+        return true;
+    }
+};
 template <typename T, int KROT>
 struct Gemm8Phase {
     static constexpr int BM = 256, BN = 256, NT = 512, MI = 8, NI = 4;
@@ -178,8 +211,9 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
                                                            int M, int N, int K, int tiles_m, int tiles_n, EpiParams ep) {
     using ML = Gemm8Phase<bf16_t, KROT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-    const int tile_m = t / tiles_n, tile_n = t % tiles_n;
+    const TileWalk walk(tiles_m, tiles_n, K);
+    int tile_m, tile_n;
+    if (!walk.coords(blockIdx.x, tile_m, tile_n)) return;
     const int m0 = tile_m * 256, n0 = tile_n * 256;
     f32x4 acc[ML::NI][ML::MI];
 #ifdef ARX_STAMP
@@ -224,10 +258,12 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
     const uint16_t* Wg = reinterpret_cast<const uint16_t*>(W);
     const int ntiles = tiles_m * tiles_n, stride = gridDim.x, nk = K >> 6;
 
+    const TileWalk walk(tiles_m, tiles_n, K);
     auto tile_of = [&](int o, int& m0, int& n0, int& ko) {
-        const int t = xcd_remap(o, ntiles);
-        const int tm = t / tiles_n, tn = t - tm * tiles_n;
+        int tm = 0, tn = 0;
+        const bool ok = walk.coords(o, tm, tn);
         m0 = tm * 256; n0 = tn * 256; ko = (tn * KROT) % nk;
+        return ok;
     };
     auto kcol = [&](int kt, int ko) { int k = kt + ko; return (k >= nk ? k - nk : k) << 6; };
 
@@ -298,9 +334,8 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
     };
 
     int orig = blockIdx.x;
-    if (orig >= ntiles) return;
     int m0, n0, ko;
-    tile_of(orig, m0, n0, ko);
+    if (!tile_of(orig, m0, n0, ko)) return;
     set_aoff(0, m0); set_aoff(1, m0); set_boff(0, n0); set_boff(1, n0);
     int sbuf = 0;                                                // epilogue-vector stage of the current tile (alternates)
     epi_stage_issue<MODE>(ep, m0, n0, smem + ML::STAGE_OFF, wid, lane);
@@ -312,9 +347,8 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
 
     for (;;) {
         const int onext = orig + stride;
-        const bool has_next = onext < ntiles;
         int m0n = 0, n0n = 0, kon = 0;
-        if (has_next) tile_of(onext, m0n, n0n, kon);
+        const bool has_next = tile_of(onext, m0n, n0n, kon);
         // interior -> interior tile steps move every source offset by a block-uniform amount
         const bool edge = (m0 + 256 > M) || (m0n + 256 > M);
         const uint32_t d_a = (uint32_t)(m0n - m0) * (uint32_t)lda, d_b = (uint32_t)(n0n - n0) * (uint32_t)ldw;

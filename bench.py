@@ -170,7 +170,7 @@ def main():
             traffic = json.loads(tj.read_text()).get("gemm_fc1_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"kernel": "gemm_v0e2_kernel<256,256,2,4,EPI_LN_BIAS_GELU,67> (FFN-1: LN1 folded, [T,768]x[3072,768]^T + erf-GELU)", "bound": "mfma",
+    roofline = {"kernel": "gemm_8phase_persistent_kernel<EPI_LN_BIAS_GELU> (FFN-1: LN1 folded, [T,768]x[3072,768]^T + erf-GELU)", "bound": "mfma",
                 "achieved": round(ach / 1e12, 1), "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_BF16, 4), "traffic": traffic,
                 "flops_per_launch": gemm_flops[dom]}
