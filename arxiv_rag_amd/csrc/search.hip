@@ -14,6 +14,7 @@
 
 #include "arx_common.h"
 #include "gemm.h"
+#include "gemm8.h"
 
 #define GROUP_ROWS 64
 #define KMAX 32                      // largest k
@@ -41,7 +42,15 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
     // rows are addressed relative to the tile so 32-bit row math stays in range for any shard size
     const int rows_here = (int)((n_rows - n0) < 256 ? (n_rows - n0) : 256);
     // k rotation by query tile: the tiles_q blocks that share this corpus tile do not miss on the same lines at once
-    ML::run(Q, D, nq, C + n0 * D, D, rows_here, D, m0, 0, smem, acc, tile_q * 2);
+    if constexpr (BM == 256 && GLDS) {      // large query batches are MFMA-bound: the encoder's 4-phase schedule (gemm8.h)
+#ifdef ARX_STAMP
+        unsigned long long dummy_stamp;
+        Gemm8Phase<f16_t, 2>::run(Q, D, nq, C + n0 * D, D, rows_here, D, m0, 0, smem, acc, tile_q * 2, dummy_stamp);
+#else
+        Gemm8Phase<f16_t, 2>::run(Q, D, nq, C + n0 * D, D, rows_here, D, m0, 0, smem, acc, tile_q * 2);
+#endif
+    } else
+        ML::run(Q, D, nq, C + n0 * D, D, rows_here, D, m0, 0, smem, acc, tile_q * 2);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wm = wid / 4, wn = wid % 4;
     if (wn * GROUP_ROWS >= rows_here) return;
@@ -392,15 +401,16 @@ template <int BM, bool GLDS>
 static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D, float* gmax, int64_t ldg, hipStream_t st) {
     using ML = GemmMainloop<f16_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
     auto kern = search_groupmax_kernel<BM, GLDS>;
+    constexpr int smem_bytes = (BM == 256 && GLDS) ? Gemm8Phase<f16_t, 2>::STAGE_OFF : ML::SMEM_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ML::SMEM_BYTES));
+        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes));
         attr_set = true;
     }
     const int tq = cdiv(nq, BM);
     const int64_t tn = (n_rows + 255) / 256;
     ARX_REQUIRE(tq * tn < (1ll << 31), "grid too large");
-    kern<<<(int)(tq * tn), 512, ML::SMEM_BYTES, st>>>(Q, nq, C, n_rows, D, tq, (int)tn, gmax, ldg);
+    kern<<<(int)(tq * tn), 512, smem_bytes, st>>>(Q, nq, C, n_rows, D, tq, (int)tn, gmax, ldg);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }

@@ -377,6 +377,38 @@ def test_persistent_gemm_bitwise_equals_per_tile_kernel(hip):
         assert (outs[2][rows].float() - want).abs().max().item() < 0.02 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("variant", [8, 9])
+def test_gemm_counted_wait_schedule_race_screen(hip, variant):
+    """The 4-phase kernels order LDS-DMA data by counted vmcnt + barriers only; an early read would show up as rare wrong
+    tiles.  Screen: 30 back-to-back launches per shape under memory load (a copy stream running beside them) must all be
+    bit-identical to the first, whose sampled rows match an fp32 matmul."""
+    lib = hip.load()
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    st = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream()
+    junk_a = torch.empty((1 << 28,), dtype=torch.uint8, device="cuda"); junk_b = torch.empty_like(junk_a)
+    for (M, N, K, mode) in ((16384, 768, 768, 2), (8192, 3072, 768, 1), (8192, 768, 3072, 2), (4099, 2304, 768, 0), (1024, 256, 128, 0)):
+        A = torch.randn((M, K), device="cuda", generator=g).to(torch.bfloat16)
+        W = (torch.randn((N, K), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn((N,), device="cuda", generator=g)
+        R = torch.randn((M, N), device="cuda", generator=g).to(torch.bfloat16)
+        first = None
+        for it in range(30):
+            with torch.cuda.stream(side):
+                junk_b.copy_(junk_a, non_blocking=True)
+            out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+            hip.check(lib.arx_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, mode,
+                                        variant, st), "arx_gemm_bf16")
+            if first is None:
+                first = out
+                want = A[:512].float() @ W.float().T + b
+                want = torch.nn.functional.gelu(want) if mode == 1 else want + R[:512].float() if mode == 2 else want
+                assert (out[:512].float() - want).abs().max().item() < 0.02 * max(1.0, want.abs().max().item())
+            else:
+                assert torch.equal(out.view(torch.int16), first.view(torch.int16)), (variant, M, N, K, mode, it)
+        torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("env", [{"ARX_LN_FOLD": "0"}, {"ARX_ATTN_VARIANT": "0"}, {"ARX_GEMM_VARIANT": "3"},
                                  {"ARX_GEMM_VARIANT": "13"}, {"ARX_GEMM_VARIANT": "8"}, {"ARX_GEMM_VARIANT": "9"}])
 def test_alternative_schedules_agree(hip, golden_dir, env, monkeypatch):
