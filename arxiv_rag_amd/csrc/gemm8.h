@@ -409,10 +409,15 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             quad(1, 0, wf0);
             if (go1 || wr == 0) ML::bar();
         }
+        // Both wave groups run their epilogues TOGETHER (sharing the VALU, 12.6 k cycles for FFN-1) instead of one after the
+        // other (8.1 k + 8.1 k, the second under a stalled partner): group 0 sits out the one interval in which group 1
+        // finishes its last MFMA section, and group 1 gives the lead back after its epilogue.  Barrier counts stay equal.
+        if (has_next && wr == 0) ML::bar();
 #ifdef ARX_STAMP
         const unsigned long long pts1 = __builtin_readcyclecounter();
 #endif
         epilogue_store_v3<MODE>(acc, ep, m0, n0, wr, wc, lane, M, smem + ML::STAGE_OFF + sbuf * EpiStage::BYTES);
+        if (has_next && wr == 1) ML::bar();
 #ifdef ARX_STAMP
         if (ep.stamps && (tid == 0 || tid == 256)) {
             unsigned long long* o = ep.stamps + ((size_t)orig * 2 + (tid >> 8)) * 4;
