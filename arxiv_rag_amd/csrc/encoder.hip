@@ -255,6 +255,7 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
         return ARX_ERR_ARG;
     }
     const bool wide = (N % 256 == 0);
+    const bool wide8 = (N % 128 == 0 && N >= 256);      // the 4-phase kernels also take a half-present last n-tile (MiniLM: N = 384, 1152)
     static bool a0 = false, a1 = false, a2 = false, a3 = false, a4 = false, a5 = false, a6 = false, a7 = false, a8 = false, a9 = false;
     if constexpr (MODE <= EPI_BIAS_RESID) {
         // first-version kernels (8-B stores, erff GELU): kept as the in-tree A/B reference for the epilogue work
@@ -270,7 +271,7 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
     // 89 = DEFAULT: persistent kernel where the epilogue has no residual stream (QKV, FFN-1: +1..4 % measured in situ), per-tile
     // kernel for the residual/statistics epilogues (their persistent form spills and is 10-20 % slower)
     if (variant == 89) variant = (MODE == EPI_BIAS || MODE == EPI_BIAS_GELU || MODE == EPI_LN_BIAS || MODE == EPI_LN_BIAS_GELU) ? 9 : 8;
-    if (variant == 9 && wide && (K / 64) % 2 == 0 && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {   // persistent 4-phase schedule
+    if (variant == 9 && wide8 && (K / 64) % 2 == 0 && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {   // persistent 4-phase schedule
         static bool r9 = false;
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; ARX_HIP_CHECK(hipGetDevice(&dev)); ARX_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)); }
@@ -283,7 +284,7 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
         ARX_HIP_CHECK(hipGetLastError());
         return ARX_OK;
     }
-    if (variant == 8 && wide && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {      // 4-phase-per-k-tile schedule (gemm8.h)
+    if (variant == 8 && wide8 && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {      // 4-phase-per-k-tile schedule (gemm8.h)
         static bool r8 = false;
         auto kern = gemm_8phase_kernel<MODE>;
         if (!r8) { ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8Phase<bf16_t, 2>::SMEM_BYTES)); r8 = true; }

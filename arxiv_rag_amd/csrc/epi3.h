@@ -14,7 +14,7 @@ struct EpiStage {
 };
 
 template <int MODE>
-__device__ __forceinline__ void epi_stage_issue(const EpiParams& p, int m0, int n0, char* stage, int wid, int lane) {
+__device__ __forceinline__ void epi_stage_issue(const EpiParams& p, int m0, int n0, char* stage, int wid, int lane, int N) {
     constexpr bool LN_IN = (MODE == EPI_LN_BIAS || MODE == EPI_LN_BIAS_GELU);
     constexpr bool LNR = (MODE == EPI_LNRESID_STATS);
     const int w = wid;                                           // wave-uniform (readfirstlane'd by the caller): scalar select and branch
@@ -32,8 +32,10 @@ __device__ __forceinline__ void epi_stage_issue(const EpiParams& p, int m0, int 
         if (w == EpiStage::RRSTD) src = p.r_sq + m0;
     }
     // lane id recomputed by v_mbcnt (two VALU ops) rather than kept live or spilled across the k-loop
-    const unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     (void)lane;
+    // a last n-tile that is only half there (N % 256 == 128): the column vectors end at N; lanes past it re-read the valid half
+    if (w < EpiStage::AMEAN && n0 + 256 > N) l &= 31;
     if (src) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + l * 4), (lds_void_t*)(stage + w * 1024), 16, 0, 0);
 }
 
@@ -154,7 +156,8 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
 
 template <int MODE>
 __device__ __forceinline__ void epilogue_store_v3(const f32x4 (&acc)[4][8], const EpiParams& p, int m0, int n0, int wr, int wc,
-                                                  int lane, int M, const char* stage) {
+                                                  int lane, int M, int N, const char* stage) {
+    if (n0 + wc * 64 >= N) return;            // N % 256 == 128: the right half of the last n-tile does not exist (wave-uniform)
     if (m0 + wr * 128 + 128 <= M) epilogue_store_v3_impl<MODE, false>(acc, p, m0, n0, wr, wc, lane, M, stage);
     else {
         epilogue_store_v3_impl<MODE, true>(acc, p, m0, n0, wr, wc, lane, M, stage);

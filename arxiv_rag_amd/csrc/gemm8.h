@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
 #ifdef ARX_STAMP
     const unsigned long long ts0 = __builtin_readcyclecounter();
 #endif
-    epi_stage_issue<MODE>(ep, m0, n0, smem + ML::STAGE_OFF, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);   // oldest loads of the tile
+    epi_stage_issue<MODE>(ep, m0, n0, smem + ML::STAGE_OFF, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, N);   // oldest loads of the tile
 #ifdef ARX_STAMP
     unsigned long long ts1 = 0;
     ML::run(A, lda, M, W, ldw, N, K, m0, n0, smem, acc, tile_n * KROT, ts1);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
 #ifdef ARX_STAMP
     const unsigned long long ts2 = __builtin_readcyclecounter();
 #endif
-    epilogue_store_v3<MODE>(acc, ep, m0, n0, wid >> 2, wid & 3, lane, M, smem + ML::STAGE_OFF);
+    epilogue_store_v3<MODE>(acc, ep, m0, n0, wid >> 2, wid & 3, lane, M, N, smem + ML::STAGE_OFF);
 #ifdef ARX_STAMP
     if (ep.stamps && (threadIdx.x == 0 || threadIdx.x == 256)) {
         unsigned long long* o = ep.stamps + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 4;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
     if (!tile_of(orig, m0, n0, ko)) return;
     set_aoff(0, m0); set_aoff(1, m0); set_boff(0, n0); set_boff(1, n0);
     int sbuf = 0;                                                // epilogue-vector stage of the current tile (alternates)
-    epi_stage_issue<MODE>(ep, m0, n0, smem + ML::STAGE_OFF, wid, lane);
+    epi_stage_issue<MODE>(ep, m0, n0, smem + ML::STAGE_OFF, wid, lane, N);
     issue_b(0, kcol(0, ko), 0); issue_a(0, kcol(0, ko), 0); issue_b(1, kcol(0, ko), 0); issue_a(1, kcol(0, ko), 0);
     issue_b(0, kcol(1, ko), 1); issue_a(0, kcol(1, ko), 1); issue_b(1, kcol(1, ko), 1);
     wait_vmcnt<6>();
@@ -351,6 +351,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
         const bool has_next = tile_of(onext, m0n, n0n, kon);
         // interior -> interior tile steps move every source offset by a block-uniform amount
         const bool edge = (m0 + 256 > M) || (m0n + 256 > M);
+        const bool nclamp = (n0 + 256 > N) || (n0n + 256 > N);
         const uint32_t d_a = (uint32_t)(m0n - m0) * (uint32_t)lda, d_b = (uint32_t)(n0n - n0) * (uint32_t)ldw;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             __builtin_amdgcn_sched_barrier(0);
             read_a(cur, 0);
             if (kt == nk - 1 && has_next)                        // next tile's epilogue vectors: ahead of (older than) its A1 pieces
-                epi_stage_issue<MODE>(ep, m0n, n0n, smem + ML::STAGE_OFF + (sbuf ^ 1) * EpiStage::BYTES, wid, lane);
+                epi_stage_issue<MODE>(ep, m0n, n0n, smem + ML::STAGE_OFF + (sbuf ^ 1) * EpiStage::BYTES, wid, lane, N);
             if (!more1 && has_next) {                            // the stream's A1 pieces now come from the next tile
                 if (edge) { asm volatile("" : "+s"(m0n)); set_aoff(1, m0n); }      // clamped rows: recompute (last tile row only)
                 else { aoff[1][0] += d_a; aoff[1][1] += d_a; }
@@ -386,7 +387,8 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             // ---- phase 2
             read_b(cur, 1, wf1);
             if (kt == nk - 2 && has_next) {
-                boff[0][0] += d_b; boff[0][1] += d_b; boff[1][0] += d_b; boff[1][1] += d_b;   // N % 256 == 0: never clamped
+                if (nclamp) { asm volatile("" : "+s"(n0n)); set_boff(0, n0n); set_boff(1, n0n); }   // half-present last n-tile: clamped rows
+                else { boff[0][0] += d_b; boff[0][1] += d_b; boff[1][0] += d_b; boff[1][1] += d_b; }
                 if (edge) { asm volatile("" : "+s"(m0n)); set_aoff(0, m0n); }
                 else { aoff[0][0] += d_a; aoff[0][1] += d_a; }
             }
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
 #ifdef ARX_STAMP
         const unsigned long long pts1 = __builtin_readcyclecounter();
 #endif
-        epilogue_store_v3<MODE>(acc, ep, m0, n0, wr, wc, lane, M, smem + ML::STAGE_OFF + sbuf * EpiStage::BYTES);
+        epilogue_store_v3<MODE>(acc, ep, m0, n0, wr, wc, lane, M, N, smem + ML::STAGE_OFF + sbuf * EpiStage::BYTES);
         if (has_next && wr == 1) ML::bar();
 #ifdef ARX_STAMP
         if (ep.stamps && (tid == 0 || tid == 256)) {
