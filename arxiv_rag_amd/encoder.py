@@ -227,7 +227,8 @@ class HipSentenceEncoder:
         self.max_seq_length = cfg.max_seq_length
         self.encoder = HipEncoder(cfg, state_dict, device=device)
         self.max_batch = max_batch
-        self.slab_texts = 8192          # texts tokenised per feeder step
+        self.slab_texts = 8192          # texts tokenised per feeder step (steady state)
+        self.first_slab_texts = 1024    # the first step is small so the GPU starts early; steps double up to slab_texts
 
     def get_sentence_embedding_dimension(self) -> int:
         return self.cfg.hidden
@@ -249,18 +250,25 @@ class HipSentenceEncoder:
         sentences = list(sentences)
         bs = max(1, min(batch_size, self.max_batch))
         slab = max(bs, self.slab_texts)
-        if len(sentences) <= slab:
+        first = max(bs, self.first_slab_texts)
+        if len(sentences) <= first:
             emb = self.encoder.encode_ragged(self.tokenize(sentences), batch_size=bs, normalize=normalize_embeddings)
         else:
-            # feeder: the tokenizer (Rust, releases the GIL) works on slab i+1 in a helper thread while the GPU encodes slab i
+            # feeder: the tokenizer (Rust, releases the GIL) works on slab i+1 in a helper thread while the GPU encodes slab i;
+            # slabs grow 1024, 2048, ... up to slab_texts so the GPU starts after ~25 ms of tokenisation, not a whole slab
             from concurrent.futures import ThreadPoolExecutor
+            bounds, size, s0 = [], first, 0
+            while s0 < len(sentences):
+                bounds.append((s0, min(len(sentences), s0 + size)))
+                s0 += size
+                size = min(slab, size * 2)
             parts = []
             with ThreadPoolExecutor(max_workers=1) as ex:
-                fut = ex.submit(self.tokenize, sentences[:slab])
-                for s0 in range(0, len(sentences), slab):
+                fut = ex.submit(self.tokenize, sentences[bounds[0][0]:bounds[0][1]])
+                for bi in range(len(bounds)):
                     seqs = fut.result()
-                    if s0 + slab < len(sentences):
-                        fut = ex.submit(self.tokenize, sentences[s0 + slab:s0 + 2 * slab])
+                    if bi + 1 < len(bounds):
+                        fut = ex.submit(self.tokenize, sentences[bounds[bi + 1][0]:bounds[bi + 1][1]])
                     parts.append(self.encoder.encode_ragged(seqs, batch_size=bs, normalize=normalize_embeddings))
             emb = np.concatenate(parts, 0)
         if convert_to_tensor:

@@ -524,7 +524,7 @@ def test_encode_feeder_slabs_and_device_rows(hip):
     words = ["ab", "cd", "graph", "x", "lattice", "qed", "zz"]
     texts = [" ".join(rs.choice(words, size=rs.randint(1, 30))) for _ in range(300)] + [""]
     one = hipm.encode(texts, batch_size=32, normalize_embeddings=True)
-    hipm.slab_texts = 64
+    hipm.slab_texts = 64; hipm.first_slab_texts = 16
     many = hipm.encode(texts, batch_size=32, normalize_embeddings=True)
     assert np.array_equal(one, many)
     dev = hipm.encode_device(texts, batch_size=32, normalize_embeddings=True)
