@@ -268,9 +268,9 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
             return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, false, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, false>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a7);
         }
     }
-    // 89 = DEFAULT: persistent kernel where the epilogue has no residual stream (QKV, FFN-1: +1..4 % measured in situ), per-tile
-    // kernel for the residual/statistics epilogues (their persistent form spills and is 10-20 % slower)
-    if (variant == 89) variant = (MODE == EPI_BIAS || MODE == EPI_BIAS_GELU || MODE == EPI_LN_BIAS || MODE == EPI_LN_BIAS_GELU) ? 9 : 8;
+    // 89 = DEFAULT: persistent kernel for the short-K shapes (K <= 1024: QKV, O-projection, FFN-1 — the per-tile first-load latency is
+    // 10-14 % of such a tile; +2..4 % measured in situ, same box), per-tile kernel for the long-K one (FFN-2: -3 % when persistent)
+    if (variant == 89) variant = (K <= 1024) ? 9 : 8;
     if (variant == 9 && wide8 && (K / 64) % 2 == 0 && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {   // persistent 4-phase schedule
         static bool r9 = false;
         static int n_cu = 0;

@@ -39,10 +39,10 @@ __device__ __forceinline__ void epi_stage_issue(const EpiParams& p, int m0, int 
     if (src) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + l * 4), (lds_void_t*)(stage + w * 1024), 16, 0, 0);
 }
 
-template <int MODE, bool CHECK>
+template <int MODE, bool CHECK, int DEPTH>
 __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8], const EpiParams& p, int m0, int n0, int wr, int wc,
                                                        int lane, int M, const char* stage) {
-    constexpr int NI = 4, MI = 8, NS = (NI / 2) * MI, DEPTH = 8;      // NS (column pair, row block) steps; residual loads DEPTH steps ahead
+    constexpr int NI = 4, MI = 8, NS = (NI / 2) * MI;                 // NS (column pair, row block) steps; residual loads DEPTH steps ahead
     constexpr bool LN_IN = (MODE == EPI_LN_BIAS || MODE == EPI_LN_BIAS_GELU);
     constexpr bool STATS = (MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS);
     constexpr bool RESID = (MODE == EPI_BIAS_RESID || STATS);
@@ -154,13 +154,13 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
     }
 }
 
-template <int MODE>
+template <int MODE, int DEPTH = 8>
 __device__ __forceinline__ void epilogue_store_v3(const f32x4 (&acc)[4][8], const EpiParams& p, int m0, int n0, int wr, int wc,
                                                   int lane, int M, int N, const char* stage) {
     if (n0 + wc * 64 >= N) return;            // N % 256 == 128: the right half of the last n-tile does not exist (wave-uniform)
-    if (m0 + wr * 128 + 128 <= M) epilogue_store_v3_impl<MODE, false>(acc, p, m0, n0, wr, wc, lane, M, stage);
+    if (m0 + wr * 128 + 128 <= M) epilogue_store_v3_impl<MODE, false, DEPTH>(acc, p, m0, n0, wr, wc, lane, M, stage);
     else {
-        epilogue_store_v3_impl<MODE, true>(acc, p, m0, n0, wr, wc, lane, M, stage);
+        epilogue_store_v3_impl<MODE, true, DEPTH>(acc, p, m0, n0, wr, wc, lane, M, stage);
         __builtin_amdgcn_s_waitcnt(0x0F70);      // see epilogue_store_v2
     }
 }

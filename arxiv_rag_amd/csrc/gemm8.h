@@ -418,7 +418,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
 #ifdef ARX_STAMP
         const unsigned long long pts1 = __builtin_readcyclecounter();
 #endif
-        epilogue_store_v3<MODE>(acc, ep, m0, n0, wr, wc, lane, M, N, smem + ML::STAGE_OFF + sbuf * EpiStage::BYTES);
+        epilogue_store_v3<MODE, (MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS) ? 4 : 8>(acc, ep, m0, n0, wr, wc, lane, M, N, smem + ML::STAGE_OFF + sbuf * EpiStage::BYTES);   // statistics modes: a 4-step residual window keeps the kernel under 256 VGPRs
         if (has_next && wr == 1) ML::bar();
 #ifdef ARX_STAMP
         if (ep.stamps && (tid == 0 || tid == 256)) {
