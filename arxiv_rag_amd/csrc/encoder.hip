@@ -276,20 +276,20 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
         static int n_cu = 0;
         if (!n_cu) { int dev = 0; ARX_HIP_CHECK(hipGetDevice(&dev)); ARX_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)); }
         auto kern = gemm_8phase_persistent_kernel<MODE>;
-        if (!r9) { ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8Phase<bf16_t, 2>::SMEM_BYTES)); r9 = true; }
+        if (!r9) { ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8Phase<bf16_t, 0>::SMEM_BYTES)); r9 = true; }
         const int tm = cdiv(M, 256), tn = cdiv(N, 256);
         int grid = TileWalk::grid(tm, tn) < n_cu ? TileWalk::grid(tm, tn) : n_cu;
         grid = grid / 8 * 8 > 0 ? grid / 8 * 8 : grid;            // a multiple of 8: a block keeps its XCD across tiles
-        kern<<<grid, 512, Gemm8Phase<bf16_t, 2>::SMEM_BYTES, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
+        kern<<<grid, 512, Gemm8Phase<bf16_t, 0>::SMEM_BYTES, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
         ARX_HIP_CHECK(hipGetLastError());
         return ARX_OK;
     }
     if (variant == 8 && wide8 && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {      // 4-phase-per-k-tile schedule (gemm8.h)
         static bool r8 = false;
         auto kern = gemm_8phase_kernel<MODE>;
-        if (!r8) { ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8Phase<bf16_t, 2>::SMEM_BYTES)); r8 = true; }
+        if (!r8) { ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8Phase<bf16_t, 0>::SMEM_BYTES)); r8 = true; }
         const int tm = cdiv(M, 256), tn = cdiv(N, 256);
-        kern<<<TileWalk::grid(tm, tn), 512, Gemm8Phase<bf16_t, 2>::SMEM_BYTES, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
+        kern<<<TileWalk::grid(tm, tn), 512, Gemm8Phase<bf16_t, 0>::SMEM_BYTES, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
         ARX_HIP_CHECK(hipGetLastError());
         return ARX_OK;
     }

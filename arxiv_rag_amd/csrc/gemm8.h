@@ -205,7 +205,7 @@ struct Gemm8Phase {
     }
 };
 
-template <int MODE, int KROT = 2>
+template <int MODE, int KROT = 0>
 __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                            const bf16_t* __restrict__ W, int64_t ldw,
                                                            int M, int N, int K, int tiles_m, int tiles_n, EpiParams ep) {
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
 // through the tile boundary: the seven free issue slots of a tile's last two k-tiles carry the first seven half-tiles of the
 // next tile (exactly what the per-tile prologue above issues), so the first-load latency (~4 us) is paid once per CU instead of
 // once per tile, and the three half-tiles in flight land under the epilogue.  Needs an even number of k-tiles (buffer parity).
-template <int MODE, int KROT = 2>
+template <int MODE, int KROT = 0>
 __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                                       const bf16_t* __restrict__ W, int64_t ldw,
                                                                       int M, int N, int K, int tiles_m, int tiles_n, EpiParams ep) {
