@@ -523,10 +523,12 @@ def test_encode_feeder_slabs_and_device_rows(hip):
     rs = np.random.RandomState(5)
     words = ["ab", "cd", "graph", "x", "lattice", "qed", "zz"]
     texts = [" ".join(rs.choice(words, size=rs.randint(1, 30))) for _ in range(300)] + [""]
-    one = hipm.encode(texts, batch_size=32, normalize_embeddings=True)
+    one = hipm.encode(texts, batch_size=32, normalize_embeddings=True)         # coalesced: one 301-sequence forward
+    hipm.coalesce_batches = False
+    small = hipm.encode(texts, batch_size=32, normalize_embeddings=True)       # the caller's batches, as given
     hipm.slab_texts = 64; hipm.first_slab_texts = 16
-    many = hipm.encode(texts, batch_size=32, normalize_embeddings=True)
-    assert np.array_equal(one, many)
+    many = hipm.encode(texts, batch_size=32, normalize_embeddings=True)        # feeder path, several slabs
+    assert np.array_equal(one, small) and np.array_equal(one, many)           # rows do not depend on batch composition
     dev = hipm.encode_device(texts, batch_size=32, normalize_embeddings=True)
     assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), one)
     want = orm.encode(texts, batch_size=32, normalize_embeddings=True)
