@@ -52,6 +52,11 @@ EXPORTS = {
                                    C.c_void_p]),
     "arx_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
+    "arx_wp_create": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "arx_wp_destroy": (None, [C.c_void_p]),
+    "arx_wp_encode": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "arx_wp_version": (C.c_int32, []),
     "arx_adjacent_cosine": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "arx_f32_to_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "arx_fill_unit_rows_f16": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_void_p]),

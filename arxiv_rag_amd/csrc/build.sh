@@ -10,6 +10,9 @@ for f in runtime encoder search; do
   hipcc $FLAGS -c $f.hip -o ../_build/$f.o ${ARX_HIPCC_EXTRA} &
   pids+=($!)
 done
+# host-only part of the C ABI (WordPiece feeder): plain C++, no device code
+g++ -O3 -std=c++17 -fPIC -pthread -c wordpiece.cpp -o ../_build/wordpiece.o &
+pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT ../_build/runtime.o ../_build/encoder.o ../_build/search.o
+hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o $OUT ../_build/runtime.o ../_build/encoder.o ../_build/search.o ../_build/wordpiece.o
 echo "built $(realpath $OUT)"

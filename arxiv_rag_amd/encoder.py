@@ -189,6 +189,32 @@ class HipEncoder:
         out[np.asarray(order)] = dev_out.cpu().numpy()
         return out
 
+    def encode_packed(self, ids: np.ndarray, lens: np.ndarray, batch_size: int = 256, normalize: bool = True,
+                      on_device: bool = False):
+        """`encode_ragged` for a tokenizer that already produced a right-padded id matrix (int32 [n, W]) and lengths: no
+        per-token Python objects anywhere on the host path.  Same length-sorted batching, same rows."""
+        n = int(len(lens))
+        if n == 0:
+            return (torch.zeros((0, self.cfg.hidden), dtype=torch.float32, device=self.device) if on_device
+                    else np.zeros((0, self.cfg.hidden), np.float32))
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        order = np.argsort(-lens.astype(np.int64), kind="stable")
+        dev_out = torch.empty((n, self.cfg.hidden), dtype=torch.float32, device=self.device)
+        for s0 in range(0, n, batch_size):
+            idx = order[s0:s0 + batch_size]
+            bl = lens[idx]
+            ml = max(int(bl.max()), 1)
+            d_ids = torch.from_numpy(np.ascontiguousarray(ids[idx, :ml], dtype=np.int32)).to(self.device, non_blocking=True)
+            d_lens = torch.from_numpy(np.ascontiguousarray(bl)).to(self.device, non_blocking=True)
+            self.forward_tokens(d_ids, d_lens, ml, max(int(bl.sum()), 1), out=dev_out[s0:s0 + len(idx)], normalize=normalize)
+        if on_device:
+            out = torch.empty_like(dev_out)
+            out[torch.from_numpy(order).to(self.device)] = dev_out
+            return out
+        out = np.empty((n, self.cfg.hidden), np.float32)
+        out[order] = dev_out.cpu().numpy()
+        return out
+
     def tap_hidden(self, ids: np.ndarray, lens: np.ndarray, layer: int) -> np.ndarray:
         """Parity tap: packed hidden state [sum(lens), H] f32 after `layer` (0 = embeddings)."""
         _lib.check(self.lib.arx_encoder_set_tap(self._handle, layer), "arx_encoder_set_tap")
@@ -240,11 +266,22 @@ class HipSentenceEncoder:
     def tokenize(self, sentences: Sequence[str]) -> List[List[int]]:
         return self.tokenizer.encode_batch(list(sentences), self.max_seq_length)
 
+    def _tokenize_any(self, sentences: Sequence[str]):
+        """-> ("packed", ids, lens) from a tokenizer with `encode_batch_packed` (the native feeder), else ("ragged", lists)."""
+        if hasattr(self.tokenizer, "encode_batch_packed"):
+            ids, lens = self.tokenizer.encode_batch_packed(list(sentences), self.max_seq_length)
+            return ("packed", ids, lens)
+        return ("ragged", self.tokenize(sentences))
+
+    def _encode_tokens_any(self, toks, bs: int, normalize: bool, on_device: bool = False):
+        if toks[0] == "packed":
+            return self.encoder.encode_packed(toks[1], toks[2], batch_size=bs, normalize=normalize, on_device=on_device)
+        return self.encoder.encode_ragged(toks[1], batch_size=bs, normalize=normalize, on_device=on_device)
+
     def encode_device(self, sentences: Sequence[str], batch_size: int = 32, normalize_embeddings: bool = False) -> torch.Tensor:
         """Rows stay in HBM (f32 [n, D], input order) — for GPU-side consumers (adjacent cosine, the search index)."""
         bs = max(1, min(batch_size, self.max_batch))
-        return self.encoder.encode_ragged(self.tokenize(list(sentences)), batch_size=bs, normalize=normalize_embeddings,
-                                          on_device=True)
+        return self._encode_tokens_any(self._tokenize_any(list(sentences)), bs, normalize_embeddings, on_device=True)
 
     def encode(self, sentences, batch_size: int = 32, show_progress_bar=None, convert_to_numpy: bool = True,
                convert_to_tensor: bool = False, normalize_embeddings: bool = False, **_ignored):
@@ -256,9 +293,9 @@ class HipSentenceEncoder:
         slab = max(bs, self.slab_texts)
         first = max(bs, self.first_slab_texts)
         if len(sentences) <= first:
-            emb = self.encoder.encode_ragged(self.tokenize(sentences), batch_size=bs, normalize=normalize_embeddings)
+            emb = self._encode_tokens_any(self._tokenize_any(sentences), bs, normalize_embeddings)
         else:
-            # feeder: the tokenizer (Rust, releases the GIL) works on slab i+1 in a helper thread while the GPU encodes slab i;
+            # feeder: the tokenizer (native C++ or Rust; both release the GIL) works on slab i+1 in a helper thread while the GPU encodes slab i;
             # slabs grow 1024, 2048, ... up to slab_texts so the GPU starts after ~25 ms of tokenisation, not a whole slab
             from concurrent.futures import ThreadPoolExecutor
             bounds, size, s0 = [], first, 0
@@ -268,12 +305,12 @@ class HipSentenceEncoder:
                 size = min(slab, size * 2)
             parts = []
             with ThreadPoolExecutor(max_workers=1) as ex:
-                fut = ex.submit(self.tokenize, sentences[bounds[0][0]:bounds[0][1]])
+                fut = ex.submit(self._tokenize_any, sentences[bounds[0][0]:bounds[0][1]])
                 for bi in range(len(bounds)):
                     seqs = fut.result()
                     if bi + 1 < len(bounds):
-                        fut = ex.submit(self.tokenize, sentences[bounds[bi + 1][0]:bounds[bi + 1][1]])
-                    parts.append(self.encoder.encode_ragged(seqs, batch_size=bs, normalize=normalize_embeddings))
+                        fut = ex.submit(self._tokenize_any, sentences[bounds[bi + 1][0]:bounds[bi + 1][1]])
+                    parts.append(self._encode_tokens_any(seqs, bs, normalize_embeddings))
             emb = np.concatenate(parts, 0)
         if convert_to_tensor:
             emb = torch.from_numpy(emb)

@@ -8,16 +8,107 @@ nothing is fetched by name.
 """
 from __future__ import annotations
 
+import ctypes
+import json
+import os
 from pathlib import Path
-from typing import List, Sequence
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
 
 from .config import ARCH_MPNET, EncoderConfig
+
+
+def _blob(strings: Sequence[bytes]) -> Tuple[bytes, np.ndarray]:
+    off = np.zeros(len(strings) + 1, np.int64)
+    if strings:
+        np.cumsum(np.fromiter(map(len, strings), np.int64, len(strings)), out=off[1:])
+    return b"".join(strings), off
+
+
+class _NativeWordPiece:
+    """arx_wp_* (include/arx.h, csrc/wordpiece.cpp): the ASCII restriction of the BERT WordPiece pipeline, multi-threaded,
+    writing an id matrix directly.  Built only when the HF pipeline is exactly the one it restates (`_native_spec`)."""
+
+    def __init__(self, vocab: dict, unk: int, bos: int, eos: int, pad: int, lowercase: bool, max_chars: int, triggers: Sequence[str]):
+        from . import _lib
+        self._libmod = _lib
+        self.lib = _lib.load()
+        toks = [b""] * (max(vocab.values()) + 1)
+        for t, i in vocab.items():
+            toks[i] = t.encode("utf-8")
+        vb, vo = _blob(toks)
+        tb, to = _blob([t.encode("utf-8") for t in triggers])
+        self._h = ctypes.c_void_p(None)
+        rc = self.lib.arx_wp_create(vb, vo.ctypes.data, len(toks), unk, bos, eos, pad, int(lowercase), max_chars,
+                                    tb, to.ctypes.data, len(triggers), ctypes.byref(self._h))
+        if rc != 0:
+            raise _lib.ArxError(f"arx_wp_create failed (rc={rc})")
+        self.pad = pad
+        self.threads = max(1, min(32, (os.cpu_count() or 8)))
+
+    def encode(self, texts: Sequence[str], max_len: int):
+        n = len(texts)
+        enc = [t.encode("utf-8") for t in texts]
+        blob, off = _blob(enc)
+        ids = np.empty((n, max_len), np.int32)
+        lens = np.zeros(n, np.int32)
+        fb = np.zeros(n, np.uint8)
+        rc = self.lib.arx_wp_encode(self._h, blob, off.ctypes.data, n, max_len, ids.ctypes.data, lens.ctypes.data,
+                                    fb.ctypes.data, self.threads)
+        if rc != 0:
+            raise self._libmod.ArxError(f"arx_wp_encode failed (rc={rc})")
+        return ids, lens, fb
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.arx_wp_destroy(self._h)
+        except Exception:
+            pass
+
+
+def _native_spec(tok) -> Optional[dict]:
+    """The native tokenizer is used only when the HF pipeline is exactly BertNormalizer(clean_text) -> BertPreTokenizer ->
+    WordPiece('##') -> TemplateProcessing '<bos> $A <eos>' (one special on each side); anything else keeps the HF path."""
+    try:
+        j = json.loads(tok.to_str())
+        nm, pt, md, pp = j.get("normalizer") or {}, j.get("pre_tokenizer") or {}, j.get("model") or {}, j.get("post_processor") or {}
+        if nm.get("type") != "BertNormalizer" or not nm.get("clean_text", False) or not nm.get("handle_chinese_chars", True):
+            return None
+        lowercase = bool(nm.get("lowercase", True))
+        if nm.get("strip_accents") not in (None, lowercase):      # accents only matter off-ASCII, but keep the pipelines identical
+            return None
+        if pt.get("type") != "BertPreTokenizer" or md.get("type") != "WordPiece" or md.get("continuing_subword_prefix") != "##":
+            return None
+        if pp.get("type") != "TemplateProcessing":
+            return None
+        single = pp.get("single") or []
+        if len(single) != 3 or "SpecialToken" not in single[0] or "Sequence" not in single[1] or "SpecialToken" not in single[2]:
+            return None
+        sp = pp.get("special_tokens") or {}
+        bos = sp[single[0]["SpecialToken"]["id"]]["ids"][0]
+        eos = sp[single[2]["SpecialToken"]["id"]]["ids"][0]
+        vocab = md["vocab"]
+        unk = vocab[md["unk_token"]]
+        triggers = [a["content"] for a in j.get("added_tokens") or []]
+        pad = j.get("padding") or {}
+        return {"vocab": vocab, "unk": unk, "bos": bos, "eos": eos, "lowercase": lowercase,
+                "max_chars": int(md.get("max_input_chars_per_word", 100)), "triggers": triggers, "pad_hint": pad.get("pad_id")}
+    except Exception:
+        return None
 
 
 class WordPieceTokenizer:
     def __init__(self, tok, cfg: EncoderConfig):
         self._tok = tok
         self.cfg = cfg
+        self._native = None
+        self.use_native = os.environ.get("ARX_NATIVE_TOKENIZER", "1") != "0"
+        spec = _native_spec(tok) if self.use_native else None
+        if spec is not None and spec["max_chars"] <= 100:
+            self._native = _NativeWordPiece(spec["vocab"], spec["unk"], spec["bos"], spec["eos"], cfg.pad_id, spec["lowercase"],
+                                            spec["max_chars"], spec["triggers"])
 
     @classmethod
     def from_dir(cls, path: str | Path, cfg: EncoderConfig) -> "WordPieceTokenizer":
@@ -60,6 +151,28 @@ class WordPieceTokenizer:
         max_len-2 word pieces for single sentences)."""
         self._tok.enable_truncation(max_length=max_len)
         return [e.ids for e in self._tok.encode_batch(list(texts))]
+
+    def encode_batch_packed(self, texts: Sequence[str], max_len: int) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (ids int32 [n, max_len] right-padded with cfg.pad_id, lens int32 [n]); same ids as `encode_batch`.
+        Pure-ASCII texts go through the native multi-threaded tokenizer, the rest (and everything, when the HF pipeline is not the
+        plain BERT WordPiece one) through HF `tokenizers`."""
+        texts = list(texts)
+        if self._native is None:
+            seqs = self.encode_batch(texts, max_len)
+            ids = np.full((len(seqs), max_len), self.cfg.pad_id, np.int32)
+            lens = np.fromiter(map(len, seqs), np.int32, len(seqs))
+            for i, s in enumerate(seqs):
+                ids[i, :len(s)] = s
+            return ids, lens
+        ids, lens, fb = self._native.encode(texts, max_len)
+        rest = np.flatnonzero(fb)
+        if rest.size:
+            seqs = self.encode_batch([texts[i] for i in rest], max_len)
+            for i, s in zip(rest, seqs):
+                ids[i, :len(s)] = s
+                ids[i, len(s):] = self.cfg.pad_id
+                lens[i] = len(s)
+        return ids, lens
 
 
 class TokenIdPassthrough:

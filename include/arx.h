@@ -151,6 +151,21 @@ int32_t arx_gemm_bf16(const void* A, const void* W, const float* bias, const voi
  * emb device f32 [n, ld >= dim]; out device f32 [n-1]. */
 int32_t arx_adjacent_cosine(const float* emb, int64_t ld, int32_t n, int32_t dim, float* out, void* stream);
 
+/* ---- host-side WordPiece feeder (no device code) ------------------------------------------------------------------------------
+ * Replaces, for pure-ASCII texts, the tokenisation sentence-transformers performs inside `model.encode(batch, ...)`
+ * (/root/reference/4-embed/generation/generate_embeddings_parallel.py:146-153; HF `tokenizers` pipeline BertNormalizer ->
+ * BertPreTokenizer -> WordPiece("##") -> "<bos> $A <eos>" -> truncation, transformers models/mpnet/tokenization_mpnet.py:108-163).
+ * Texts with a byte >= 0x80 or containing one of the `triggers` (the tokenizer's added-token strings) are FLAGGED, not tokenised:
+ * the caller sends them through the reference pipeline.  Multi-threaded; writes a padded id matrix and lengths directly. */
+int32_t arx_wp_create(const char* vocab_blob, const int64_t* vocab_off /* [n_vocab+1] */, int32_t n_vocab, int32_t unk_id,
+                      int32_t bos_id, int32_t eos_id, int32_t pad_id, int32_t lowercase, int32_t max_chars_per_word,
+                      const char* trigger_blob, const int64_t* trigger_off /* [n_triggers+1] */, int32_t n_triggers, void** out);
+void arx_wp_destroy(void* tokenizer);
+/* ids: host int32 [n, max_len] (rows padded with pad_id), lens: host int32 [n], fallback: host uint8 [n] (1 = not tokenised here) */
+int32_t arx_wp_encode(void* tokenizer, const char* text_blob, const int64_t* text_off /* [n+1] */, int64_t n, int32_t max_len,
+                      int32_t* ids, int32_t* lens, uint8_t* fallback, int32_t n_threads);
+int32_t arx_wp_version(void);
+
 /* ---- small device helpers the host code needs (all on `stream`) -------------------------------- */
 /* f32 [n] -> bf16 [n] round-to-nearest-even (weight upload). */
 int32_t arx_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);

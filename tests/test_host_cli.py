@@ -184,6 +184,66 @@ def test_tokenizer_from_dir_vocab_txt(tmp_path):
 
 
 # ------------------------------------------------------------------ C ABI
+@pytest.mark.parametrize("preset", ["all-mpnet-base-v2", "all-MiniLM-L6-v2"])
+def test_native_wordpiece_equals_hf_pipeline_and_oracle(preset):
+    """arx_wp_* (csrc/wordpiece.cpp) against the HF `tokenizers` pipeline it restates on ASCII, and against the Python
+    restatement in oracle/: fuzzed ASCII (punctuation runs, control bytes, over-long words, upper case), truncation at several
+    max_len, and non-ASCII / added-token texts that must take the fallback and still come back identical."""
+    cfg = C.PRESETS[preset]
+    vocab = synthetic_vocab(C.EncoderConfig(**{**cfg.__dict__, "vocab_size": 6000}))
+    tok = WordPieceTokenizer.from_vocab(vocab, cfg)
+    assert tok._native is not None, "native tokenizer not engaged for the plain BERT WordPiece pipeline"
+    rs = np.random.RandomState(3)
+    words = [w for w in vocab if w.isalpha()][:1500]
+    alphabet = list("abcXYZ019 .,;!?-()[]{}<>#$%^&*_+=~`'\"/\\|@:\t\n\r\x0b\x0c\x00\x1f\x7f")
+    texts = []
+    for _ in range(1500):
+        parts = []
+        for _ in range(rs.randint(0, 50)):
+            r = rs.rand()
+            if r < 0.6:
+                parts.append(rs.choice(words))
+            elif r < 0.8:
+                parts.append("".join(rs.choice(alphabet, size=rs.randint(1, 8))))
+            elif r < 0.85:
+                parts.append("x" * rs.randint(95, 110))
+            else:
+                parts.append(rs.choice(words).upper() + rs.choice(words))
+        texts.append((" " if rs.rand() < 0.9 else "").join(parts))
+    texts += ["", " ", "\t\n", "é accents ünï", "naïve café", "中文 text", "a" * 100, "b" * 101, "<s> literal", "[UNK] x", "##ab ##"]
+    arch_mpnet = cfg.arch == C.ARCH_MPNET
+    for max_len in (cfg.max_seq_length, 16, 5, 2):
+        want = tok.encode_batch(texts, max_len)                              # HF pipeline
+        ids, lens = tok.encode_batch_packed(texts, max_len)                  # native + fallback
+        assert ids.shape == (len(texts), max_len) and ids.dtype == np.int32
+        for i, w in enumerate(want):
+            assert list(ids[i, :lens[i]]) == w, (max_len, texts[i][:60])
+            assert (ids[i, lens[i]:] == cfg.pad_id).all()
+    for t in texts[:300] + texts[-11:]:
+        assert TO.encode(t, vocab, arch_mpnet, cfg.max_seq_length) == list(
+            (lambda r: r[0][0, :r[1][0]])(tok.encode_batch_packed([t], cfg.max_seq_length)))
+    # the flags themselves: ASCII rows are native, the rest fall back
+    _, _, fb = tok._native.encode(["plain ascii", "caf\u00e9", ""], 8)
+    assert fb.tolist() == [0, 1, 0]
+
+
+def test_native_wordpiece_respects_added_tokens(tmp_path):
+    """A tokenizer.json with added special tokens: texts that contain one of them literally are not tokenised natively."""
+    cfg = C.TINY_BERT
+    vocab = synthetic_vocab(cfg)
+    base = WordPieceTokenizer.from_vocab(vocab, cfg)
+    base._tok.add_special_tokens(["[SEP]", "[CLS]", "[UNK]"])
+    base._tok.save(str(tmp_path / "tokenizer.json"))
+    tok = WordPieceTokenizer.from_dir(tmp_path, cfg)
+    assert tok._native is not None
+    texts = ["ab cd", "ab [SEP] cd", "x [unk] y", "[CLS]"]
+    want = tok.encode_batch(texts, 16)
+    ids, lens = tok.encode_batch_packed(texts, 16)
+    assert [list(ids[i, :lens[i]]) for i in range(len(texts))] == want
+    _, _, fb = tok._native.encode(texts, 16)
+    assert fb.tolist() == [0, 1, 0, 1]
+
+
 def test_cabi_exports_every_declared_symbol():
     from arxiv_rag_amd import _lib
     hdr = (ROOT / "include" / "arx.h").read_text()

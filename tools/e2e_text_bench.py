@@ -23,8 +23,11 @@ rs = np.random.RandomState(0)
 texts = [" ".join(rs.choice(words, size=rs.randint(60, 260))) for _ in range(n)]
 model = HipSentenceEncoder(cfg, seeded_state_dict(cfg, seed=0), tok)
 model.encode(texts[:2048], batch_size=1024, normalize_embeddings=True)           # warm
-t0 = time.time(); seqs = model.tokenize(texts); t_tok = time.time() - t0
+t0 = time.time(); seqs = model.tokenize(texts); t_tok_hf = time.time() - t0
+t0 = time.time(); _, lens_ = tok.encode_batch_packed(texts, cfg.max_seq_length); t_tok = time.time() - t0
 ntok = sum(len(s) for s in seqs)
+assert int(lens_.sum()) == ntok
+print(json.dumps({"tokenizer_hf_s": round(t_tok_hf, 3), "tokenizer_native_s": round(t_tok, 3), "native": tok._native is not None}))
 for bs in (200, 1024):
     t0 = time.time(); emb = model.encode(texts, batch_size=bs, normalize_embeddings=True); t = time.time() - t0
     print(json.dumps({"chunks": n, "tokens": ntok, "mean_tokens": round(ntok / n, 1), "batch_size": bs,
