@@ -116,6 +116,41 @@ def generate_embeddings_worker(args: Tuple[List[str], str, int, int]) -> Tuple[i
         return (batch_idx, [], msg)
 
 
+def _encode_quanta(texts: List[str], q_lo: int, q_hi: int, model_name: str, batch_size: int, chunks_per_worker: int,
+                   super_quanta: int = 32):
+    """Quanta [q_lo, q_hi) -> yields (qi, rows, err) exactly as `generate_embeddings_worker` would, but fast: a HIP sentence
+    encoder gets `super_quanta` quanta per `encode()` call (rows do not depend on how texts are batched, so the result is the same;
+    the tokenizer feeder and the 1024-sequence forwards then run at the device-bound rate instead of 200 texts at a time).  Any
+    exception or row-count mismatch in a fast call falls back to the per-quantum worker, i.e. to the reference's policy
+    (sub-batch retry, per-item retry, zero rows; GEN:131-177)."""
+    model = None
+    try:
+        model = get_worker_model(model_name)
+    except Exception:
+        model = None
+    fast = model is not None and getattr(model, "coalesce_batches", False)
+    qi = q_lo
+    while qi < q_hi:
+        qe = min(q_hi, qi + (super_quanta if fast else 1))
+        a, b = qi * chunks_per_worker, min(len(texts), qe * chunks_per_worker)
+        rows = None
+        if fast:
+            try:
+                rows = model.encode(texts[a:b], batch_size=batch_size, normalize_embeddings=True, show_progress_bar=False,
+                                    convert_to_numpy=True, convert_to_tensor=False)
+                if len(rows) != b - a:
+                    rows = None
+            except Exception:
+                rows = None
+        for q in range(qi, qe):
+            qa, qb = q * chunks_per_worker, min(len(texts), (q + 1) * chunks_per_worker)
+            if rows is not None:
+                yield (q, list(rows[qa - a:qb - a]), None)
+            else:
+                yield generate_embeddings_worker((texts[qa:qb], model_name, batch_size, q))
+        qi = qe
+
+
 def _dist():
     import torch.distributed as dist
     return dist if (dist.is_available() and dist.is_initialized()) else None
@@ -143,8 +178,7 @@ def generate_embeddings_parallel(chunks: List[Dict], model_name: str = "all-mpne
     q_lo, q_hi = shard_range(len(quanta), world, rank)
     done: Dict[int, List[np.ndarray]] = {}
     errors: List[str] = []
-    for q in quanta[q_lo:q_hi]:
-        idx, rows, err = generate_embeddings_worker(q)
+    for idx, rows, err in _encode_quanta(texts, q_lo, q_hi, model_name, batch_size, chunks_per_worker):
         if err:
             errors.append(f"Batch {idx}: {err}")
         if rows:
@@ -198,9 +232,8 @@ def generate_embeddings_sharded(chunks: List[Dict], model_name: str, batch_size:
     dim = get_worker_model(model_name).get_sentence_embedding_dimension()
     rows = np.zeros((hi - lo, dim), np.float32)
     errors = 0
-    for qi in range(q_lo, q_hi):
-        a, b = qi * chunks_per_worker, min(len(texts), (qi + 1) * chunks_per_worker)
-        idx, got, err = generate_embeddings_worker((texts[a:b], model_name, batch_size, qi))
+    for idx, got, err in _encode_quanta(texts, q_lo, q_hi, model_name, batch_size, chunks_per_worker):
+        a, b = idx * chunks_per_worker, min(len(texts), (idx + 1) * chunks_per_worker)
         if err or len(got) != b - a:
             errors += 1
             print(f"Warning: Batch {idx} produced {len(got)} of {b - a} embeddings; missing rows stay zero")

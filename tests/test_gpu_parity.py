@@ -517,6 +517,47 @@ def test_cli_text_to_files_gpu_vs_oracle_model(hip, tmp_path, monkeypatch):
     hipm.encoder.close()
 
 
+def test_cli_fast_path_keeps_the_reference_error_policy(hip, tmp_path, monkeypatch):
+    """The dispatcher hands a HIP encoder many quanta per encode() call; when such a call raises, it must fall back to the
+    per-quantum worker and end where the reference ends (GEN:155-169): only the offending chunk becomes a zero row, every other
+    row is what an undisturbed run produces."""
+    import json
+    from arxiv_rag_amd import generate_embeddings_parallel as GEN
+    from tests.helpers import make_chunk_tree
+    cfg, hipm, _ = _tiny_text_models()
+    make_chunk_tree(tmp_path / "in", n_files=5, chunks_per_file=9, seed=5)
+    victim = sorted((tmp_path / "in").rglob("*.json"))[2]
+    doc = json.loads(victim.read_text())
+    doc["chunks"][4]["text"] = "poison " + doc["chunks"][4]["text"]
+    victim.write_text(json.dumps(doc))
+
+    class Poisoned:
+        coalesce_batches = True
+        def __init__(self, inner): self.inner, self.calls = inner, []
+        def get_sentence_embedding_dimension(self): return self.inner.get_sentence_embedding_dimension()
+        def encode(self, texts, **kw):
+            self.calls.append(len(texts))
+            if any(t.startswith("poison") for t in texts):
+                raise RuntimeError("injected")
+            return self.inner.encode(texts, **kw)
+
+    outs = {}
+    for tag, model in (("clean", hipm), ("poisoned", Poisoned(hipm))):
+        (tmp_path / tag).mkdir(); monkeypatch.chdir(tmp_path / tag)
+        assert GEN.main([str(tmp_path / "in"), "--min-quality", "0.0", "--skip-chroma", "--batch-size", "8", "--chunks-per-worker", "10"],
+                        model_factory=lambda name, m=model: m) == 0
+        outs[tag] = (np.load(tmp_path / tag / "embeddings_saved" / "embeddings.npy"),
+                     json.loads((tmp_path / tag / "embeddings_saved" / "metadata.json").read_text()), model)
+    ec, mc, _ = outs["clean"]; ep, mp_, pm = outs["poisoned"]
+    assert mc == mp_ and ec.shape == ep.shape
+    zero = [i for i in range(len(ep)) if not ep[i].any()]
+    assert len(zero) == 1 and mc[zero[0]]["chunk_id"] == doc["chunks"][4].get("chunk_id", mc[zero[0]]["chunk_id"])
+    keep = [i for i in range(len(ep)) if i != zero[0]]
+    assert np.array_equal(ec[keep], ep[keep])                  # identical rows: batching never changes a row
+    assert pm.calls[0] == 45 and 1 in pm.calls                 # one fast call over all quanta first, per-item retries at the end
+    hipm.encoder.close()
+
+
 def test_encode_feeder_slabs_and_device_rows(hip):
     """encode(): the multi-slab feeder path returns the same rows as one slab; encode_device keeps input order."""
     cfg, hipm, orm = _tiny_text_models()
