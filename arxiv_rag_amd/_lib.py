@@ -56,6 +56,10 @@ EXPORTS = {
                                   C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "arx_wp_destroy": (None, [C.c_void_p]),
     "arx_wp_encode": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "arx_wp_miss_count": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "arx_wp_miss_fetch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "arx_wp_cache_add": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "arx_wp_cache_size": (C.c_int64, [C.c_void_p]),
     "arx_wp_version": (C.c_int32, []),
     "arx_adjacent_cosine": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "arx_f32_to_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

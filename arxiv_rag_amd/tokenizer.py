@@ -47,9 +47,10 @@ class _NativeWordPiece:
         self.pad = pad
         self.threads = max(1, min(32, (os.cpu_count() or 8)))
 
-    def encode(self, texts: Sequence[str], max_len: int):
-        n = len(texts)
-        enc = [t.encode("utf-8") for t in texts]
+    MAX_CACHED_SEGMENTS = 4_000_000
+
+    def _encode_raw(self, enc: Sequence[bytes], max_len: int):
+        n = len(enc)
         blob, off = _blob(enc)
         ids = np.empty((n, max_len), np.int32)
         lens = np.zeros(n, np.int32)
@@ -58,6 +59,42 @@ class _NativeWordPiece:
                                     fb.ctypes.data, self.threads)
         if rc != 0:
             raise self._libmod.ArxError(f"arx_wp_encode failed (rc={rc})")
+        return ids, lens, fb
+
+    def misses(self) -> List[bytes]:
+        ns, nb = ctypes.c_int64(0), ctypes.c_int64(0)
+        self.lib.arx_wp_miss_count(self._h, ctypes.byref(ns), ctypes.byref(nb))
+        if ns.value == 0:
+            return []
+        buf = ctypes.create_string_buffer(max(1, nb.value))
+        off = np.zeros(ns.value + 1, np.int64)
+        self.lib.arx_wp_miss_fetch(self._h, buf, off.ctypes.data)
+        raw = buf.raw
+        return [raw[off[i]:off[i + 1]] for i in range(ns.value)]
+
+    def teach(self, segments: Sequence[bytes], pieces: Sequence[Sequence[int]]):
+        sb, so = _blob(list(segments))
+        io = np.zeros(len(pieces) + 1, np.int64)
+        if pieces:
+            np.cumsum(np.fromiter(map(len, pieces), np.int64, len(pieces)), out=io[1:])
+        flat = np.fromiter((t for p in pieces for t in p), np.int32, int(io[-1])) if io[-1] else np.zeros(1, np.int32)
+        rc = self.lib.arx_wp_cache_add(self._h, sb, so.ctypes.data, len(segments), flat.ctypes.data, io.ctypes.data)
+        if rc != 0:
+            raise self._libmod.ArxError(f"arx_wp_cache_add failed (rc={rc})")
+
+    def encode(self, texts: Sequence[str], max_len: int, resolve=None):
+        """-> (ids, lens, fallback).  `resolve(list of segment strings) -> list of piece-id lists` is the reference pipeline applied
+        to lone segments (no specials, no truncation); with it, texts whose only obstacle was an unseen non-ASCII segment are
+        re-encoded after the segments have been learnt, and come back with fallback 0."""
+        enc = [t.encode("utf-8") for t in texts]
+        ids, lens, fb = self._encode_raw(enc, max_len)
+        todo = np.flatnonzero(fb == 2)
+        if todo.size and resolve is not None and self.lib.arx_wp_cache_size(self._h) < self.MAX_CACHED_SEGMENTS:
+            segs = self.misses()
+            self.teach(segs, resolve([s.decode("utf-8") for s in segs]))
+            ids2, lens2, fb2 = self._encode_raw([enc[i] for i in todo], max_len)
+            ids[todo], lens[todo], fb[todo] = ids2, lens2, fb2
+        fb[fb == 2] = 1                                          # anything still unresolved takes the whole-text fallback
         return ids, lens, fb
 
     def __del__(self):
@@ -152,6 +189,11 @@ class WordPieceTokenizer:
         self._tok.enable_truncation(max_length=max_len)
         return [e.ids for e in self._tok.encode_batch(list(texts))]
 
+    def _segment_pieces(self, segments: Sequence[str]) -> List[List[int]]:
+        """The HF pipeline on lone whitespace-delimited segments: no specials, no truncation (what the native cache stores)."""
+        self._tok.no_truncation()
+        return [e.ids for e in self._tok.encode_batch(list(segments), add_special_tokens=False)]
+
     def encode_batch_packed(self, texts: Sequence[str], max_len: int) -> Tuple[np.ndarray, np.ndarray]:
         """-> (ids int32 [n, max_len] right-padded with cfg.pad_id, lens int32 [n]); same ids as `encode_batch`.
         Pure-ASCII texts go through the native multi-threaded tokenizer, the rest (and everything, when the HF pipeline is not the
@@ -164,7 +206,7 @@ class WordPieceTokenizer:
             for i, s in enumerate(seqs):
                 ids[i, :len(s)] = s
             return ids, lens
-        ids, lens, fb = self._native.encode(texts, max_len)
+        ids, lens, fb = self._native.encode(texts, max_len, resolve=self._segment_pieces)
         rest = np.flatnonzero(fb)
         if rest.size:
             seqs = self.encode_batch([texts[i] for i in rest], max_len)

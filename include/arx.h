@@ -155,8 +155,9 @@ int32_t arx_adjacent_cosine(const float* emb, int64_t ld, int32_t n, int32_t dim
  * Replaces, for pure-ASCII texts, the tokenisation sentence-transformers performs inside `model.encode(batch, ...)`
  * (/root/reference/4-embed/generation/generate_embeddings_parallel.py:146-153; HF `tokenizers` pipeline BertNormalizer ->
  * BertPreTokenizer -> WordPiece("##") -> "<bos> $A <eos>" -> truncation, transformers models/mpnet/tokenization_mpnet.py:108-163).
- * Texts with a byte >= 0x80 or containing one of the `triggers` (the tokenizer's added-token strings) are FLAGGED, not tokenised:
- * the caller sends them through the reference pipeline.  Multi-threaded; writes a padded id matrix and lengths directly. */
+ * Texts containing one of the `triggers` (the tokenizer's added-token strings) are FLAGGED, not tokenised: the caller sends them
+ * through the reference pipeline; non-ASCII segments go through a cache of that pipeline's output (below).  Multi-threaded; writes a
+ * padded id matrix and lengths directly. */
 int32_t arx_wp_create(const char* vocab_blob, const int64_t* vocab_off /* [n_vocab+1] */, int32_t n_vocab, int32_t unk_id,
                       int32_t bos_id, int32_t eos_id, int32_t pad_id, int32_t lowercase, int32_t max_chars_per_word,
                       const char* trigger_blob, const int64_t* trigger_off /* [n_triggers+1] */, int32_t n_triggers, void** out);
@@ -164,6 +165,16 @@ void arx_wp_destroy(void* tokenizer);
 /* ids: host int32 [n, max_len] (rows padded with pad_id), lens: host int32 [n], fallback: host uint8 [n] (1 = not tokenised here) */
 int32_t arx_wp_encode(void* tokenizer, const char* text_blob, const int64_t* text_off /* [n+1] */, int64_t n, int32_t max_len,
                       int32_t* ids, int32_t* lens, uint8_t* fallback, int32_t n_threads);
+/* fallback[i]: 0 = tokenised; 1 = send the whole text through the reference pipeline (added-token string present, or a non-ASCII
+ * run > 512 bytes); 2 = the text has non-ASCII whitespace-delimited segments the tokenizer has not been taught yet: fetch them
+ * (arx_wp_miss_count / arx_wp_miss_fetch), tokenise each ONCE with the reference pipeline (no specials, no truncation), hand the
+ * pieces back (arx_wp_cache_add) and encode those texts again.  tokens(text) is the concatenation of tokens(segment) because every
+ * stage of the pipeline is local to a whitespace-delimited segment. */
+int32_t arx_wp_miss_count(void* tokenizer, int64_t* n_strings, int64_t* n_bytes);
+int32_t arx_wp_miss_fetch(void* tokenizer, char* blob, int64_t* off /* [n_strings+1] */);
+int32_t arx_wp_cache_add(void* tokenizer, const char* seg_blob, const int64_t* seg_off /* [n+1] */, int64_t n, const int32_t* ids,
+                         const int64_t* ids_off /* [n+1] */);
+int64_t arx_wp_cache_size(void* tokenizer);
 int32_t arx_wp_version(void);
 
 /* ---- small device helpers the host code needs (all on `stream`) -------------------------------- */

@@ -222,9 +222,60 @@ def test_native_wordpiece_equals_hf_pipeline_and_oracle(preset):
     for t in texts[:300] + texts[-11:]:
         assert TO.encode(t, vocab, arch_mpnet, cfg.max_seq_length) == list(
             (lambda r: r[0][0, :r[1][0]])(tok.encode_batch_packed([t], cfg.max_seq_length)))
-    # the flags themselves: ASCII rows are native, the rest fall back
-    _, _, fb = tok._native.encode(["plain ascii", "caf\u00e9", ""], 8)
+    # the flags themselves: ASCII rows are native; an unseen non-ASCII segment falls back unless a resolver teaches it
+    _, _, fb = tok._native.encode(["plain ascii", "zz\u00e9qq", ""], 8)
     assert fb.tolist() == [0, 1, 0]
+    _, _, fb = tok._native.encode(["plain ascii", "zz\u00e9qq", ""], 8, resolve=tok._segment_pieces)
+    assert fb.tolist() == [0, 0, 0]
+
+
+def test_native_wordpiece_unicode_segments_equal_hf_pipeline():
+    """Non-ASCII text: the native tokenizer learns each distinct whitespace-delimited non-ASCII segment from the HF pipeline once
+    and must then reproduce HF's ids for whole texts — accents (composed and decomposed), combining marks after a space, Greek
+    incl. final sigma, dotted/dotless i, dashes and quotes, math symbols beyond the BMP, CJK (spaced out by the normaliser),
+    no-break / thin / ideographic spaces, zero-width and format characters, U+FFFD, NEL and line separator, ligatures."""
+    cfg = C.MPNET_BASE
+    vocab = synthetic_vocab(C.EncoderConfig(**{**cfg.__dict__, "vocab_size": 6000}))
+    pool = [w for w in vocab if w.isalpha() and len(w) > 4]
+    for j, e in enumerate(["\u03b1", "\u03b2", "##\u03b1", "e", "naive", "cafe", "\u2013", "\u201c", "\u4e2d", "\u6587", "ss", "i"]):
+        if e not in vocab:
+            vocab[e] = vocab.pop(pool[j])
+    tok = WordPieceTokenizer.from_vocab(vocab, cfg)
+    assert tok._native is not None
+    cps = [0x3b1, 0x3b2, 0x3b3, 0xe9, 0xe8, 0xfc, 0xf1, 0xdf, 0x131, 0x130, 0x3a3, 0x3c3, 0x3c2, 0x2013, 0x2014, 0x201c, 0x201d,
+           0x2018, 0x2019, 0x2026, 0xb7, 0xd7, 0xf7, 0xb0, 0xb1, 0xb2, 0xbd, 0x2192, 0x221e, 0x2211, 0x222b, 0x2202, 0x221a, 0x2264,
+           0x2265, 0x2260, 0x2248, 0x1d465, 0x1d538, 0x4e2d, 0x6587, 0x65e5, 0x672c, 0x8a9e, 0xd55c, 0xad6d, 0x627, 0x628, 0xa0,
+           0x2009, 0x200b, 0x200d, 0x301, 0x308, 0xfeff, 0xad, 0xfffd, 0x3000, 0x85, 0x2028, 0xfb01, 0xc5, 0x1c4, 0x1c5]
+    uni = [chr(c) for c in cps] + ["A\u030a", "o\u0308"]
+    rs = np.random.RandomState(1)
+    words = [w for w in vocab if w.isalpha() and w.isascii()][:1500]
+    texts = []
+    for _ in range(1500):
+        parts = []
+        for _ in range(rs.randint(0, 40)):
+            r = rs.rand()
+            if r < 0.55:
+                parts.append(rs.choice(words))
+            elif r < 0.75:
+                parts.append(rs.choice(words)[:3] + "".join(rs.choice(uni, size=rs.randint(1, 4))) + rs.choice(words)[:2])
+            elif r < 0.85:
+                parts.append("".join(rs.choice(uni, size=rs.randint(1, 6))))
+            elif r < 0.9:
+                parts.append(rs.choice(list(".,;-()[]\t\n\x00\x0b")))
+            else:
+                parts.append(rs.choice(words).upper())
+        texts.append((" " if rs.rand() < 0.9 else "").join(parts))
+    texts += ["\u4e2d\u6587" * 300, "\u00e9" * 200 + " x", "a\u0301", "\u0301a", " \u0301 ", "\u0130stanbul ISTANBUL \u0131i",
+              "\u03a3\u0391\u03a3 \u03c3\u03b1\u03c2", "x\u00a0y", "\ufb01nal"]
+    for max_len in (cfg.max_seq_length, 12, 3):
+        want = tok.encode_batch(texts, max_len)
+        ids, lens = tok.encode_batch_packed(texts, max_len)
+        for i, w in enumerate(want):
+            assert list(ids[i, :lens[i]]) == w, (max_len, ascii(texts[i])[:80])
+            assert (ids[i, lens[i]:] == cfg.pad_id).all()
+    _, _, fb = tok._native.encode(texts, cfg.max_seq_length, resolve=tok._segment_pieces)
+    assert int((fb == 1).sum()) == 1 and fb[-9] == 1            # only the 1800-byte unsegmented CJK run takes the whole-text fallback
+    assert tok._native.lib.arx_wp_cache_size(tok._native._h) > 1000
 
 
 def test_native_wordpiece_respects_added_tokens(tmp_path):
