@@ -271,6 +271,7 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
     // 89 = DEFAULT: persistent kernel for the short-K shapes (K <= 1024: QKV, O-projection, FFN-1 — the per-tile first-load latency is
     // 10-14 % of such a tile; +2..4 % measured in situ, same box), per-tile kernel for the long-K one (FFN-2: -3 % when persistent)
     if (variant == 89) variant = (K <= 1024) ? 9 : 8;
+    if (variant == 9 && (K / 64) % 2 != 0) variant = 8;          // the persistent form needs an even number of k-tiles (buffer parity)
     if (variant == 9 && wide8 && (K / 64) % 2 == 0 && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {   // persistent 4-phase schedule
         static bool r9 = false;
         static int n_cu = 0;
