@@ -52,6 +52,7 @@ EXPORTS = {
                                    C.c_void_p]),
     "arx_gemm_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_void_p]),
+    "arx_prof_classes": (C.c_int32, [C.c_uint32]),
     "arx_wp_create": (C.c_int32, [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     "arx_wp_destroy": (None, [C.c_void_p]),
@@ -98,6 +99,12 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().arx_last_error().decode("utf-8", "replace")
         raise ArxError(f"{what} failed (rc={rc}): {msg}")
+
+
+def prof_classes(names=None):
+    """Restrict event recording to these kernel classes (None = all)."""
+    mask = 0xFFFFFFFF if names is None else sum(1 << K_CLASSES.index(n) for n in names)
+    check(load().arx_prof_classes(mask), "arx_prof_classes")
 
 
 def prof_enable(on: bool):

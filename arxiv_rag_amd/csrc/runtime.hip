@@ -18,13 +18,14 @@ extern "C" int32_t arx_version(void) { return ARX_VERSION; }
 // ---- profiling: event pairs per kernel class, recorded on the launch stream -----------------------
 struct ProfPair { hipEvent_t a, b; };
 static bool g_prof_on = false;
+static uint32_t g_prof_mask = 0xffffffffu;      // kernel classes that record events while profiling is on
 static std::vector<ProfPair> g_pairs[ARX_K_CLASSES];
 static std::vector<ProfPair> g_free;
 
 bool arx_prof_on() { return g_prof_on; }
 
 int arx_prof_begin(int cls, hipStream_t st) {
-    if (!g_prof_on) return -1;
+    if (!g_prof_on || !((g_prof_mask >> cls) & 1u)) return -1;
     ProfPair p;
     if (!g_free.empty()) { p = g_free.back(); g_free.pop_back(); }
     else {
@@ -40,6 +41,7 @@ void arx_prof_end(int cls, int token, hipStream_t st) {
 }
 
 extern "C" int32_t arx_prof_enable(int32_t on) { g_prof_on = on != 0; return ARX_OK; }
+extern "C" int32_t arx_prof_classes(uint32_t mask) { g_prof_mask = mask; return ARX_OK; }
 extern "C" int32_t arx_prof_reset(void) {
     for (int c = 0; c < ARX_K_CLASSES; ++c) {
         for (auto& p : g_pairs[c]) g_free.push_back(p);

@@ -199,6 +199,9 @@ int32_t arx_fill_unit_rows_f16(void* dst, int64_t n_rows, int32_t dim, uint64_t 
 #define ARX_K_SEARCH_RESCORE 10
 #define ARX_K_CLASSES        11
 int32_t arx_prof_enable(int32_t on);
+/* bit c set = kernel class c (ARX_K_*) records its event pair while profiling is on (default: all).  A timed run enables only the
+ * class it reports, so that the other ~170 event packets per forward do not sit between the kernels being timed. */
+int32_t arx_prof_classes(uint32_t mask);
 int32_t arx_prof_reset(void);
 int32_t arx_prof_read(int32_t kernel_class, float* total_ms, int32_t* launches);
 
