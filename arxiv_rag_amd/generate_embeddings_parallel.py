@@ -18,6 +18,7 @@ import json
 import multiprocessing as mp
 import os
 import sys
+import threading
 import time
 import traceback
 from concurrent.futures import ThreadPoolExecutor
@@ -245,7 +246,7 @@ def generate_embeddings_sharded(chunks: List[Dict], model_name: str, batch_size:
 
 
 def save_embeddings_sharded(chunks: List[Dict], rows: np.ndarray, lo: int, hi: int,
-                            output_dir: str = "./embeddings_saved", out_dtype: str = "float64"):
+                            output_dir: str = "./embeddings_saved", out_dtype: str = "float64", prefetch=None):
     """Same three files as save_embeddings_to_disk_fallback, written cooperatively: rank 0 creates embeddings.npy
     (header + size), every rank stores its own row range through a memmap, rank 0 writes metadata/index."""
     dist = _dist()
@@ -266,13 +267,13 @@ def save_embeddings_sharded(chunks: List[Dict], rows: np.ndarray, lo: int, hi: i
     if dist:
         dist.barrier()
     if rank == 0:
-        _write_metadata_and_index(chunks, out, n, dim, nbytes)
+        _write_metadata_and_index(chunks, out, n, dim, nbytes, prefetch)
         print(f"✅ Saved {n:,} embeddings ({dim} dimensions) from {dist.get_world_size() if dist else 1} rank(s)")
 
 
 # --------------------------------------------------------------------------------------------- write
 def save_embeddings_to_disk_fallback(chunks: List[Dict], embeddings: Sequence, output_dir: str = "./embeddings_saved",
-                                     out_dtype: str = "float64"):
+                                     out_dtype: str = "float64", prefetch=None):
     """embeddings.npy (float64 C-order [N, D] — the reference's `.tolist()` round trip yields float64),
     metadata.json (indent=2, ensure_ascii=False), index.json (GEN:271-321).  Streams through a memmap so a
     5 M x 768 corpus (30.7 GB) never needs a second in-RAM copy."""
@@ -289,20 +290,59 @@ def save_embeddings_to_disk_fallback(chunks: List[Dict], embeddings: Sequence, o
     arr.flush()
     del arr
     print(f"✅ Saved embeddings to {out / 'embeddings.npy'}")
-    _write_metadata_and_index(chunks, out, n, dim, nbytes)
+    _write_metadata_and_index(chunks, out, n, dim, nbytes, prefetch)
     print(f"✅ Saved {n:,} embeddings ({dim} dimensions)")
     print(f"   Total size: ~{nbytes / 1024 / 1024 / 1024:.2f} GB")
 
 
-def _write_metadata_and_index(chunks: List[Dict], out: Path, n: int, dim: int, nbytes: int):
+def _dump_metadata(chunks: List[Dict], path: Path):
     meta = []
     for i, ch in enumerate(chunks):
         m = ch.get("metadata", {})
         meta.append({"chunk_id": ch.get("chunk_id", f"chunk_{i}"), "paper_id": m.get("paper_id"),
                      "section": m.get("section"), "quality_score": m.get("quality_score"),
                      "text": ch["text"], "text_length": len(ch["text"])})
-    with open(out / "metadata.json", "w", encoding="utf-8") as fh:
+    with open(path, "w", encoding="utf-8") as fh:
         json.dump(meta, fh, indent=2, ensure_ascii=False)
+
+
+class MetadataPrefetch(threading.Thread):
+    """metadata.json depends on the chunk list only, so its (pure-Python, ~17 us per chunk) serialisation runs beside the
+    GPU while the embeddings are being generated, into `<out>/metadata.json.partial`; the writer renames it into place at
+    the point where the reference writes the file (GEN:300-311), or discards it when the run does not get that far."""
+
+    def __init__(self, chunks: List[Dict], output_dir: str = "./embeddings_saved"):
+        super().__init__(daemon=True)
+        self.chunks, self.out, self.ok = chunks, Path(output_dir), False
+        self.partial = self.out / "metadata.json.partial"
+
+    def run(self):
+        try:
+            self.out.mkdir(parents=True, exist_ok=True)
+            _dump_metadata(self.chunks, self.partial)
+            self.ok = True
+        except Exception:                                              # noqa: BLE001  (the writer then serialises itself)
+            self.ok = False
+
+    def take(self, chunks: List[Dict], dest: Path) -> bool:
+        self.join()
+        if self.ok and chunks is self.chunks and self.partial.exists() and dest.parent.resolve() == self.out.resolve():
+            os.replace(self.partial, dest)
+            return True
+        self.discard()
+        return False
+
+    def discard(self):
+        self.join()
+        try:
+            self.partial.unlink()
+        except OSError:
+            pass
+
+
+def _write_metadata_and_index(chunks: List[Dict], out: Path, n: int, dim: int, nbytes: int, prefetch: Optional["MetadataPrefetch"] = None):
+    if prefetch is None or not prefetch.take(chunks, out / "metadata.json"):
+        _dump_metadata(chunks, out / "metadata.json")
     print(f"✅ Saved metadata to {out / 'metadata.json'}")
     index = {"total_embeddings": n, "embedding_dimension": dim, "total_size_gb": nbytes / 1024 / 1024 / 1024}
     with open(out / "index.json", "w", encoding="utf-8") as fh:
@@ -448,6 +488,7 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
     print(f"  Load workers: {args.load_workers or int(cpu_count * 0.8)}")
     print(f"  Store batch size: {args.store_batch_size}")
     print(f"  ChromaDB: {args.chroma_db}\n")
+    meta_prefetch = None
     try:
         t_start = time.time()
         chunks = load_chunks_parallel(input_dir, min_quality=args.min_quality, num_workers=args.load_workers)
@@ -462,6 +503,9 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
         except (ImportError, FileNotFoundError, OSError, RuntimeError) as e:
             print(f"Error: embedding backend not available: {e}")
             return 1
+        if rank == 0:                        # metadata.json is serialised beside the GPU work; renamed into place by the writer
+            meta_prefetch = MetadataPrefetch(chunks, "./embeddings_saved")
+            meta_prefetch.start()
         t0 = time.time()
         local_range = None
         if world > 1:
@@ -474,11 +518,14 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
         embedding_time = time.time() - t0
         print(f"Embedding generation completed in {embedding_time:.1f} seconds ({embedding_time / 60:.1f} min)\n")
         if world > 1:
-            save_embeddings_sharded(chunks, embeddings, lo, hi, output_dir="./embeddings_saved", out_dtype=args.out_dtype)
+            save_embeddings_sharded(chunks, embeddings, lo, hi, output_dir="./embeddings_saved", out_dtype=args.out_dtype,
+                                    prefetch=meta_prefetch)
         elif rank == 0:
             print("Saving embeddings to disk as backup...")
-            save_embeddings_to_disk_fallback(chunks, embeddings, output_dir="./embeddings_saved", out_dtype=args.out_dtype)
+            save_embeddings_to_disk_fallback(chunks, embeddings, output_dir="./embeddings_saved", out_dtype=args.out_dtype,
+                                             prefetch=meta_prefetch)
             print()
+        meta_prefetch = None
         if args.queries:
             qs = [ln.strip() for ln in Path(args.queries).read_text(encoding="utf-8").splitlines() if ln.strip()]
             if qs:
@@ -526,6 +573,9 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
         print(f"\n\n❌ Fatal error: {e}")
         traceback.print_exc()
         return 1
+    finally:
+        if meta_prefetch is not None:            # the run ended before the writer took the file: nothing half-written stays behind
+            meta_prefetch.discard()
 
 
 if __name__ == "__main__":

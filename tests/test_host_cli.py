@@ -98,6 +98,30 @@ def test_cli_end_to_end_order_layout_and_filter(tmp_path, tiny_model, monkeypatc
     assert max(model.calls) <= 7                           # sub-batches honour --batch-size
 
 
+def test_metadata_prefetch_is_byte_identical_and_leaves_nothing_behind(tmp_path, tiny_model, monkeypatch):
+    """metadata.json is serialised in a helper thread while the embeddings are generated and renamed into place by the writer:
+    same bytes as the writer's own serialisation, no `.partial` left after a successful run nor after a run that fails first."""
+    cfg, sd, tok = tiny_model
+    model = OracleSentenceModel(cfg, sd, tok)
+    chunks = make_chunk_tree(tmp_path / "in", n_files=4, chunks_per_file=6, seed=8)
+    monkeypatch.chdir(tmp_path)
+    assert GEN.main([str(tmp_path / "in"), "--min-quality", "0.0", "--skip-chroma"], model_factory=lambda name: model) == 0
+    out = tmp_path / "embeddings_saved"
+    assert not (out / "metadata.json.partial").exists()
+    loaded = GEN.load_chunks_parallel(tmp_path / "in", min_quality=0.0)
+    GEN._dump_metadata(loaded, tmp_path / "direct.json")
+    assert (out / "metadata.json").read_bytes() == (tmp_path / "direct.json").read_bytes()
+    # a prefetch that is never taken (the run died before the writer) removes its partial file
+    pf = GEN.MetadataPrefetch(loaded, str(tmp_path / "other"))
+    pf.start(); pf.discard()
+    assert not (tmp_path / "other" / "metadata.json.partial").exists()
+    # a prefetch for a different chunk list is not used
+    pf = GEN.MetadataPrefetch(loaded[:3], str(tmp_path / "third")); pf.start()
+    GEN.save_embeddings_to_disk_fallback(loaded, [np.zeros(4)] * len(loaded), output_dir=str(tmp_path / "third"), prefetch=pf)
+    assert len(json.loads((tmp_path / "third" / "metadata.json").read_text())) == len(loaded)
+    assert not (tmp_path / "third" / "metadata.json.partial").exists()
+
+
 def test_cli_exit_codes(tmp_path, tiny_model, monkeypatch):
     cfg, sd, tok = tiny_model
     monkeypatch.chdir(tmp_path)
