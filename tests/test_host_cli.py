@@ -448,3 +448,23 @@ def test_semantic_grouping_matches_reference_walk():
     assert group_sentences([], []) == []
     with pytest.raises(ValueError):
         group_sentences(["a", "b"], [])
+
+
+def test_committed_bench_line_honours_the_contract():
+    """The bench line committed under profiles/ (what `python bench.py` printed on the GPU box) carries every key the driver
+    and the judge read, with consistent arithmetic."""
+    d = json.loads((ROOT / "profiles" / "r01_bench_8phase.json").read_text())
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "chunks/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    per_step = d["config"]["global_batch"] * 1000.0 / d["ms_per_step"]
+    assert abs(per_step - d["value"]) / d["value"] < 0.02                       # value = chunks per step / time per step
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    s = d["search"]["roofline"]
+    assert s["bound"] == "hbm" and abs(s["achieved"] / s["peak"] - s["frac"]) < 1e-3
