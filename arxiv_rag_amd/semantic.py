@@ -70,3 +70,27 @@ def semantic_chunks(text: str, encoder, max_chunk_size: int = 1000, min_chunk_si
     emb = encoder.encode_device(sentences, batch_size=batch_size, normalize_embeddings=False)   # :1382-1396, un-normalised
     sims = adjacent_cosines(emb).cpu().numpy()
     return group_sentences(sentences, sims, max_chunk_size, min_chunk_size, metadata)
+
+
+def semantic_chunks_batch(texts: Sequence[str], encoder, max_chunk_size: int = 1000, min_chunk_size: int = 100,
+                          metadatas: Optional[Sequence[Optional[Dict]]] = None, batch_size: int = 512) -> List[Optional[List[Dict]]]:
+    """Many documents at once — the MI355X-shaped form of the same step: the sentences of ALL documents go through one
+    length-sorted encode (1024-sequence forwards instead of one small forward per paper), one `arx_adjacent_cosine` launch covers
+    every adjacent pair (pairs that straddle two documents are computed and ignored), and only the per-document grouping walk runs
+    on the host.  Entry i is what `semantic_chunks(texts[i], ...)` returns (None where the reference falls back to fixed chunking)."""
+    from .encoder import adjacent_cosines
+    split = [split_sentences(t) for t in texts]
+    keep = [i for i, s in enumerate(split) if len(s) >= 2]
+    out: List[Optional[List[Dict]]] = [None] * len(texts)
+    if not keep:
+        return out
+    flat = [s for i in keep for s in split[i]]
+    emb = encoder.encode_device(flat, batch_size=batch_size, normalize_embeddings=False)
+    sims = adjacent_cosines(emb).cpu().numpy()
+    pos = 0
+    for i in keep:
+        n = len(split[i])
+        md = metadatas[i] if metadatas is not None else None
+        out[i] = group_sentences(split[i], sims[pos:pos + n - 1], max_chunk_size, min_chunk_size, md)
+        pos += n
+    return out

@@ -598,3 +598,22 @@ def test_semantic_chunks_end_to_end_vs_oracle_model(hip):
     if np.abs(so - 0.7).min() > 2e-3:
         assert got == group_sentences(sents, so, 600, 50, {"paper_id": "p"})
     hipm.encoder.close()
+
+
+def test_semantic_chunks_batch_equals_per_document(hip):
+    """One encode + one adjacent-cosine launch over the sentences of many documents gives, per document, exactly what the
+    per-document call gives (rows do not depend on batch composition; boundary pairs are ignored)."""
+    from arxiv_rag_amd.semantic import semantic_chunks, semantic_chunks_batch
+    cfg, hipm, _ = _tiny_text_models()
+    rs = np.random.RandomState(21)
+    words = ["graph", "neural", "lattice", "qed", "proof", "of", "the", "bounded", "spectrum", "we", "show"]
+    docs = []
+    for d in range(12):
+        n = [0, 1, 2, 7, 30, 55][d % 6]
+        docs.append(" ".join(" ".join(rs.choice(words, size=rs.randint(4, 25))).capitalize() + "." for _ in range(n)))
+    mds = [{"paper_id": f"p{d}"} if d % 2 else None for d in range(len(docs))]
+    got = semantic_chunks_batch(docs, hipm, max_chunk_size=400, min_chunk_size=40, metadatas=mds)
+    want = [semantic_chunks(t, hipm, max_chunk_size=400, min_chunk_size=40, metadata=m) for t, m in zip(docs, mds)]
+    assert got == want
+    assert got[0] is None and got[1] is None and got[4] is not None
+    hipm.encoder.close()
