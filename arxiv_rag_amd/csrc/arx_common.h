@@ -21,6 +21,11 @@ void arx_set_error(const char* fmt, ...);
 // per-kernel-class event timing (runtime.hip); token < 0 = profiling off
 int arx_prof_begin(int cls, hipStream_t st);
 void arx_prof_end(int cls, int token, hipStream_t st);
+// hipFuncAttributeMaxDynamicSharedMemorySize, raised at most once per (device, kernel, size): the attribute belongs to the
+// device's code object, so a second handle on another GPU of the same process must set it again (runtime.hip; thread-safe)
+hipError_t arx_func_smem(const void* kernel, int bytes);
+// compute units of the CURRENT device (cached per device)
+int arx_device_cus();
 struct ProfScope {
     int cls, tok; hipStream_t st;
     ProfScope(int c, hipStream_t s) : cls(c), tok(arx_prof_begin(c, s)), st(s) {}

@@ -103,6 +103,12 @@ extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_e
                         L.b_fc2 && L.ln2_g && L.ln2_b, "layer %d: missing weights", i);
     }
     arx_encoder* h = new arx_encoder();
+    auto fail = [&](int code) {                        // every error exit releases whatever the handle already owns
+        if (h->ws) (void)hipFree(h->ws);
+        if (h->fold_ws) (void)hipFree(h->fold_ws);
+        delete h;
+        return code;
+    };
     h->cfg = *cfg;
     h->w = *w;
     h->layers.assign(w->layers, w->layers + cfg->layers);
@@ -114,14 +120,16 @@ extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_e
     h->variant = e ? atoi(e) : 89;
     const char* av = getenv("ARX_ATTN_VARIANT");
     h->attn_variant = av ? atoi(av) : 1;
-    const char* g = getenv("ARX_GEMM_GLDS");          // legacy switch: 0 = register-staged reference loop
+#ifdef ARX_DEV_VARIANTS
+    const char* g = getenv("ARX_GEMM_GLDS");          // dev switch: 0 = register-staged reference loop
     if (g && g[0] == '0') h->variant = 4;
+#endif
     const WsLayout l = ws_layout(*cfg, max_tokens, max_seqs);
     hipError_t he = hipMalloc((void**)&h->ws, l.total);
     if (he != hipSuccess) {
         arx_set_error("hipMalloc(%lld bytes workspace): %s", (long long)l.total, hipGetErrorString(he));
-        delete h;
-        return ARX_ERR_HIP;
+        h->ws = nullptr;
+        return fail(ARX_ERR_HIP);
     }
     h->ws_bytes = l.total;
     // padded rows are read by GEMM tiles (results discarded): keep them finite
@@ -149,9 +157,8 @@ extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_e
         he = hipMalloc((void**)&h->fold_ws, per * Lc);
         if (he != hipSuccess) {
             arx_set_error("hipMalloc(folded weights): %s", hipGetErrorString(he));
-            (void)hipFree(h->ws);
-            delete h;
-            return ARX_ERR_HIP;
+            h->fold_ws = nullptr;
+            return fail(ARX_ERR_HIP);
         }
         char* pws = h->fold_ws;
         auto takep = [&](int64_t bytes) { char* r = pws; pws += round_up64(bytes, 256); return r; };
@@ -171,9 +178,7 @@ extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_e
         he = hipDeviceSynchronize();
         if (he != hipSuccess) {
             arx_set_error("fold_ln_kernel: %s", hipGetErrorString(he));
-            (void)hipFree(h->ws); (void)hipFree(h->fold_ws);
-            delete h;
-            return ARX_ERR_HIP;
+            return fail(ARX_ERR_HIP);
         }
     }
     if (cfg->arch == ARX_ARCH_MPNET) {
@@ -182,9 +187,7 @@ extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_e
         he = hipMemcpy(rb.data(), w->rel_bias, rb.size() * 4, hipMemcpyDeviceToHost);
         if (he != hipSuccess) {
             arx_set_error("copy rel_bias: %s", hipGetErrorString(he));
-            (void)hipFree(h->ws);
-            delete h;
-            return ARX_ERR_HIP;
+            return fail(ARX_ERR_HIP);
         }
         std::vector<float> tbl((size_t)cfg->heads * ARX_BIAS_ROW);
         const float log2e = 1.4426950408889634f;
@@ -196,9 +199,7 @@ extern "C" int32_t arx_encoder_create(const arx_encoder_config* cfg, const arx_e
         he = hipMemcpy(h->bias_tbl, tbl.data(), tbl.size() * 4, hipMemcpyHostToDevice);
         if (he != hipSuccess) {
             arx_set_error("upload bias table: %s", hipGetErrorString(he));
-            (void)hipFree(h->ws);
-            delete h;
-            return ARX_ERR_HIP;
+            return fail(ARX_ERR_HIP);
         }
     }
     *out = h;
@@ -231,20 +232,22 @@ extern "C" int32_t arx_encoder_debug_hidden(arx_encoder* h, int32_t /*layer_slot
 }
 
 // ---- GEMM dispatch ------------------------------------------------------------------------------
-// variant: 0 = 2-stage loop + 8-B stores (round-1 first version), 1 = 2-stage loop + 16-B/64-B-segment epilogue,
-//          2 = ring 256x128 (4 waves, 3 half-tile slots, 2 blocks/CU), 3 = ring 256x256 (8 waves, 4 slots)
+// Shipped schedules: 89 = default (persistent 4-phase kernel for K <= 1024, per-tile 4-phase kernel above), 8 / 9 = per-tile /
+// persistent everywhere they apply, 13 = the 2-stage loop (64-bit offsets, any N % 8 == 0: the fallback for shapes the 4-phase
+// kernels do not take).  The round-1 A/B schedules (0, 1, 2, 3, 4, 15, 33, 34) are compiled only with -DARX_DEV_VARIANTS.
 template <typename Kern>
 static int launch_gemm_kernel(Kern kern, int smem, int threads, int BM, int BN, const uint16_t* A, int64_t lda,
-                              const uint16_t* W, int64_t ldw, int M, int N, int K, const EpiParams& ep, hipStream_t st,
-                              bool* attr_set) {
-    if (!*attr_set) {
-        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        *attr_set = true;
-    }
+                              const uint16_t* W, int64_t ldw, int M, int N, int K, const EpiParams& ep, hipStream_t st) {
+    ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem));
     const int tm = cdiv(M, BM), tn = cdiv(N, BN);
     kern<<<tm * tn, threads, smem, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
+}
+
+// the 4-phase kernels address operands and the output with 32-bit element offsets
+static bool fits_u32_offsets(int64_t M, int64_t lda, int64_t N, int64_t ldw, const EpiParams& ep) {
+    return M * lda < (1ll << 31) && N * ldw < (1ll << 31) && M * ep.ldc < (1ll << 32) && (!ep.resid || M * ep.ldr < (1ll << 32));
 }
 
 template <int MODE>
@@ -256,28 +259,35 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
     }
     const bool wide = (N % 256 == 0);
     const bool wide8 = (N % 128 == 0 && N >= 256);      // the 4-phase kernels also take a half-present last n-tile (MiniLM: N = 384, 1152)
-    static bool a0 = false, a1 = false, a2 = false, a3 = false, a4 = false, a5 = false, a6 = false, a7 = false, a8 = false, a9 = false;
+#ifdef ARX_DEV_VARIANTS
     if constexpr (MODE <= EPI_BIAS_RESID) {
-        // first-version kernels (8-B stores, erff GELU): kept as the in-tree A/B reference for the epilogue work
+        // first-version kernels (8-B stores, erff GELU): the A/B reference for the epilogue work
         if (variant == 0) {
-            if (wide) return launch_gemm_kernel(gemm_bf16_kernel<256, 256, 2, 4, true, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, true>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a0);
-            return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, true, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, true>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a1);
+            if (wide) return launch_gemm_kernel(gemm_bf16_kernel<256, 256, 2, 4, true, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, true>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st);
+            return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, true, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, true>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st);
         }
         if (variant == 4) {      // register-staged loop (no global_load_lds)
-            if (wide) return launch_gemm_kernel(gemm_bf16_kernel<256, 256, 2, 4, false, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, false>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a6);
-            return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, false, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, false>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a7);
+            if (wide) return launch_gemm_kernel(gemm_bf16_kernel<256, 256, 2, 4, false, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, false>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st);
+            return launch_gemm_kernel(gemm_bf16_kernel<256, 128, 4, 2, false, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, false>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st);
         }
     }
+#endif
     // 89 = DEFAULT: persistent kernel for the short-K shapes (K <= 1024: QKV, O-projection, FFN-1 — the per-tile first-load latency is
     // 10-14 % of such a tile; +2..4 % measured in situ, same box), per-tile kernel for the long-K one (FFN-2: -3 % when persistent)
     if (variant == 89) variant = (K <= 1024) ? 9 : 8;
     if (variant == 9 && (K / 64) % 2 != 0) variant = 8;          // the persistent form needs an even number of k-tiles (buffer parity)
-    if (variant == 9 && wide8 && (K / 64) % 2 == 0 && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {   // persistent 4-phase schedule
-        static bool r9 = false;
-        static int n_cu = 0;
-        if (!n_cu) { int dev = 0; ARX_HIP_CHECK(hipGetDevice(&dev)); ARX_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev)); }
+    if ((variant == 8 || variant == 9) && wide8 && !fits_u32_offsets(M, lda, N, ldw, ep)) {
+        static bool said = false;                                // once per process: the shape is served, by the slower kernel
+        if (!said) {
+            said = true;
+            fprintf(stderr, "[arx] gemm M=%d N=%d K=%d: operand or output offsets exceed 32 bits, using the 2-stage kernel (64-bit offsets)\n", M, N, K);
+        }
+        variant = 13;
+    }
+    if (variant == 9 && wide8) {                                 // persistent 4-phase schedule
         auto kern = gemm_8phase_persistent_kernel<MODE>;
-        if (!r9) { ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8Phase<bf16_t, 0>::SMEM_BYTES)); r9 = true; }
+        ARX_HIP_CHECK(arx_func_smem((const void*)kern, Gemm8Phase<bf16_t, 0>::SMEM_BYTES));
+        const int n_cu = arx_device_cus();
         const int tm = cdiv(M, 256), tn = cdiv(N, 256);
         int grid = TileWalk::grid(tm, tn) < n_cu ? TileWalk::grid(tm, tn) : n_cu;
         grid = grid / 8 * 8 > 0 ? grid / 8 * 8 : grid;            // a multiple of 8: a block keeps its XCD across tiles
@@ -285,45 +295,34 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
         ARX_HIP_CHECK(hipGetLastError());
         return ARX_OK;
     }
-    if (variant == 8 && wide8 && (int64_t)M * lda < (1ll << 31) && (int64_t)N * ldw < (1ll << 31)) {      // 4-phase-per-k-tile schedule (gemm8.h)
-        static bool r8 = false;
+    if (variant == 8 && wide8) {                                 // 4-phase-per-k-tile schedule (gemm8.h)
         auto kern = gemm_8phase_kernel<MODE>;
-        if (!r8) { ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Gemm8Phase<bf16_t, 0>::SMEM_BYTES)); r8 = true; }
+        ARX_HIP_CHECK(arx_func_smem((const void*)kern, Gemm8Phase<bf16_t, 0>::SMEM_BYTES));
         const int tm = cdiv(M, 256), tn = cdiv(N, 256);
         kern<<<TileWalk::grid(tm, tn), 512, Gemm8Phase<bf16_t, 0>::SMEM_BYTES, st>>>((const bf16_t*)A, lda, (const bf16_t*)W, ldw, M, N, K, tm, tn, ep);
         ARX_HIP_CHECK(hipGetLastError());
         return ARX_OK;
     }
-    if (variant == 34 && wide) {      // ping-pong: the two waves of a SIMD half a k-step apart
-        static bool r2 = false;
-        return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 64 + 4096>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 64 + 4096>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &r2);
+#ifdef ARX_DEV_VARIANTS
+    if (variant == 34 && wide)       // ping-pong: the two waves of a SIMD half a k-step apart
+        return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 64 + 4096>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 64 + 4096>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st);
+    if (variant == 33 && wide)       // A operand 3-deep (two k-steps ahead), W double-buffered, 160 KB LDS
+        return launch_gemm_kernel(gemm_a3w2_kernel<256, 256, 2, 4, MODE>, 3 * 256 * 128 + 2 * 256 * 128, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st);
+    if (variant == 1) {              // 2-stage loop + 16-B-store epilogue, no stagger / setprio / k rotation
+        if (wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, true>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st);
+        return launch_gemm_kernel(gemm_v0e2_kernel<256, 128, 4, 2, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, true>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st);
     }
-    if (variant == 33 && wide) {      // A operand 3-deep (two k-steps ahead), W double-buffered, 160 KB LDS
-        static bool r0 = false;
-        return launch_gemm_kernel(gemm_a3w2_kernel<256, 256, 2, 4, MODE>, 3 * 256 * 128 + 2 * 256 * 128, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &r0);
-    }
-    switch (variant) {
-    case 1:       // 2-stage loop + 16-B-store epilogue, no stagger / setprio / k rotation
-        if (wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE>, GemmMainloop<bf16_t, 256, 256, 2, 4, true>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a2);
-        return launch_gemm_kernel(gemm_v0e2_kernel<256, 128, 4, 2, MODE>, GemmMainloop<bf16_t, 256, 128, 4, 2, true>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a3);
-    case 15:      // stagger + setprio, no k rotation
-        if (wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 3>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 3>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a8);
-        [[fallthrough]];
-    case 3:       // ring 256x256, 8 waves, 4 half-tile slots
-        if (variant == 3 && wide) return launch_gemm_kernel(gemm_ring_kernel<256, 256, 2, 4, 4, MODE>, GemmRing<bf16_t, 256, 256, 2, 4, 4>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &a4);
-        [[fallthrough]];
-    case 2:       // ring 256x128, 4 waves, 3 half-tile slots, 2 blocks/CU
-        if (variant != 15) return launch_gemm_kernel(gemm_ring_kernel<256, 128, 2, 2, 3, MODE>, GemmRing<bf16_t, 256, 128, 2, 2, 3>::SMEM_BYTES, 256, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a5);
-        [[fallthrough]];
-    case 13:
-    default:      // DEFAULT: 2-stage loop, upper-half waves issue loads mid-step, setprio around MFMA clusters,
-                  // k-loop start rotated by 2*tile_n (blocks sharing an A panel do not miss on the same lines at once)
-        if (!wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 128, 4, 2, MODE, 67>, GemmMainloop<bf16_t, 256, 128, 4, 2, true, 67>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st, &a9);
-        {
-            static bool ax13 = false;
-            return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 67>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 67>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st, &ax13);
-        }
-    }
+    if (variant == 15 && wide)       // stagger + setprio, no k rotation
+        return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 3>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 3>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st);
+    if (variant == 3 && wide)        // ring 256x256, 8 waves, 4 half-tile slots
+        return launch_gemm_kernel(gemm_ring_kernel<256, 256, 2, 4, 4, MODE>, GemmRing<bf16_t, 256, 256, 2, 4, 4>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st);
+    if (variant == 2 || variant == 3)   // ring 256x128, 4 waves, 3 half-tile slots, 2 blocks/CU
+        return launch_gemm_kernel(gemm_ring_kernel<256, 128, 2, 2, 3, MODE>, GemmRing<bf16_t, 256, 128, 2, 2, 3>::SMEM_BYTES, 256, 256, 128, A, lda, W, ldw, M, N, K, ep, st);
+#endif
+    // 13: 2-stage loop, upper-half waves issue loads mid-step, setprio around MFMA clusters, k-loop start rotated by 2*tile_n
+    // (blocks sharing an A panel do not miss on the same lines at once); 64-bit offsets, any N % 8 == 0
+    if (!wide) return launch_gemm_kernel(gemm_v0e2_kernel<256, 128, 4, 2, MODE, 67>, GemmMainloop<bf16_t, 256, 128, 4, 2, true, 67>::SMEM_BYTES, 512, 256, 128, A, lda, W, ldw, M, N, K, ep, st);
+    return launch_gemm_kernel(gemm_v0e2_kernel<256, 256, 2, 4, MODE, 67>, GemmMainloop<bf16_t, 256, 256, 2, 4, true, 67>::SMEM_BYTES, 512, 256, 256, A, lda, W, ldw, M, N, K, ep, st);
 }
 
 template <int MODE>
@@ -391,11 +390,7 @@ static int launch_attn_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream_t 
     auto kern = attention_kernel<DH, HB, NW>;
     const int Lk = (max_len + 31) & ~31;
     const int smem = AttnSmem<DH>::total(Lk, HB);
-    static int attr_max = 0;
-    if (smem > attr_max) {
-        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_max = smem;
-    }
+    ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem));
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     dim3 grid(cdiv(max_len, 32 * NW), h->cfg.heads, n_seqs);
     ProfScope ps(ARX_K_ATTENTION, st);
@@ -409,11 +404,7 @@ static int launch_attn_tr_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream
     auto kern = attention_tr_kernel<DH, HB, NW>;
     const int Lk = (max_len + 31) & ~31;
     const int smem = AttnSmem3<DH>::total(Lk, HB);
-    static int attr_max = 0;
-    if (smem > attr_max) {
-        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_max = smem;
-    }
+    ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem));
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     dim3 grid(cdiv(max_len, 32 * NW), h->cfg.heads, n_seqs);
     ProfScope ps(ARX_K_ATTENTION, st);

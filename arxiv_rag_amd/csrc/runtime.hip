@@ -1,6 +1,8 @@
 // Library-wide plumbing: error string, version, per-kernel-class hipEvent timing (include/arx.h).
 #include <stdarg.h>
 
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "arx_common.h"
@@ -14,6 +16,32 @@ void arx_set_error(const char* fmt, ...) {
 }
 extern "C" const char* arx_last_error(void) { return g_err; }
 extern "C" int32_t arx_version(void) { return ARX_VERSION; }
+
+// ---- per-device launch attributes ------------------------------------------------------------------------
+static std::mutex g_attr_mu;
+static std::map<std::pair<int, const void*>, int> g_attr_smem;
+static std::map<int, int> g_dev_cus;
+
+hipError_t arx_func_smem(const void* kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    int& have = g_attr_smem[std::make_pair(dev, kernel)];
+    if (have >= bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
+
+int arx_device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    int& n = g_dev_cus[dev];
+    if (n <= 0 && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n;
+}
 
 // ---- profiling: event pairs per kernel class, recorded on the launch stream -----------------------
 struct ProfPair { hipEvent_t a, b; };

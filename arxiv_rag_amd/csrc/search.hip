@@ -18,8 +18,8 @@
 
 #define GROUP_ROWS 64
 #define KMAX 32                      // largest k
-#define KSEL_SMALL 16                 // groups rescored when k <= 10
-#define KSEL_BIG 40                   // groups rescored when k <= 32
+#define KSEL_SMALL 12                 // groups rescored when k <= 10 (k + 2: the certificate, not a margin, answers for exactness)
+#define KSEL_BIG 36                   // groups rescored when k <= 32
 #define SUPER 16                      // groups per super-group in the selection pass
 #define SEL_SPLIT_WAVES 4            // waves per select block
 #define QBATCH_MAX 1024              // queries per internal pass (bounds the gmax workspace)
@@ -163,36 +163,89 @@ __device__ __forceinline__ void wave_topk(float (&s)[R], int64_t (&id)[R], int k
     }
 }
 
-// pass B1 stage 2 + pass B2: one block of 16 waves per query; 4 block barriers in total.
-//   (1) each wave reduces its slice of the nslices*K partial super-groups to K, wave 0 reduces 16*K -> K
-//   (2) wave 0 expands to K*SUPER groups (their gmax), reduces to the K best groups
-//   (3) wave w rescoring group w (, w+16, ...): 8 lanes per corpus row, query row staged in LDS; keeps its top-k
-//   (4) wave 0 reduces 16*k -> k and writes the result
-#define RS_NT 1024
-#define RS_NW (RS_NT / 64)
-template <int K>
-__global__ __launch_bounds__(RS_NT) void rescore_kernel(const float* __restrict__ part_s, const int32_t* __restrict__ part_g,
-                                                         int nslices, int64_t ldg, const float* __restrict__ gmax,
-                                                         int64_t n_groups, const f16_t* __restrict__ Q,
-                                                         const f16_t* __restrict__ C, int64_t n_rows, int D, int k,
-                                                         float* __restrict__ out_s, int64_t* __restrict__ out_i,
-                                                         int64_t idx_base) {
+// exact score of corpus row `row` against the query row staged in LDS: 8 lanes per row (l8 = lane & 7), two FMA chains per
+// lane over its 16-B chunks, then a 3-step butterfly -> every lane of the octet holds the sum.  The ONE definition of a score
+// in this file: pass B2 and the certificate's fallback both rank by it.
+__device__ __forceinline__ float exact_row_score(const f16_t* __restrict__ crow, const f16_t* qs, int nch, int l8, bool ok) {
+    float a0 = 0.f, a1 = 0.f;
+    if (ok) {
+        int ch = l8;
+#pragma unroll 1
+        for (; ch + 24 < nch; ch += 32) {
+            f16x8 cv[4], qq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cv[u] = *reinterpret_cast<const f16x8*>(crow + (ch + 8 * u) * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) qq[u] = *reinterpret_cast<const f16x8*>(qs + (ch + 8 * u) * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    a0 = fmaf((float)cv[u][e], (float)qq[u][e], a0);
+                    a1 = fmaf((float)cv[u][e + 1], (float)qq[u][e + 1], a1);
+                }
+        }
+        for (; ch < nch; ch += 8) {
+            const f16x8 cv = *reinterpret_cast<const f16x8*>(crow + ch * 8);
+            const f16x8 qq = *reinterpret_cast<const f16x8*>(qs + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                a0 = fmaf((float)cv[e], (float)qq[e], a0);
+                a1 = fmaf((float)cv[e + 1], (float)qq[e + 1], a1);
+            }
+        }
+    }
+    float a = a0 + a1;
+    a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+    return a;
+}
+
+// pass B1 stage 2 + pass B2 + exactness certificate: one block of NT/64 waves per query.
+//   (1) each wave reduces its slice of the nslices*K partial super-groups to K+1, wave 0 reduces those to K+1: K selected
+//       super-groups + the best one left out
+//   (2) wave 0 expands to K*SUPER groups (their gmax), reduces to the K best groups + the best one left out
+//   (3) wave w rescoring group w (, w+NW, ...): 8 lanes per corpus row, query row staged in LDS; keeps its top-k
+//   (4) wave 0 reduces NW*k -> k
+//   (5) CERTIFICATE.  U = an upper bound on the pass-A score of every row that was NOT rescored = max(best super-group left out
+//       in (1), the K-th kept value of every select slice (bounds what that slice dropped), best group left out in (2)).
+//       Pass A (f16 MFMA, f32 accumulate) and pass B2 (f32 FMA chains) both approximate the real dot product, within
+//       eps_A + eps_B <= tau = tau_scale * |q|_2 for corpus rows of norm <= 1 + 2^-9 (unit rows, as the encoder writes them; tau_scale =
+//       (0.3125 D + 4) 2^-24: 8 roundings per 32-deep MFMA step, D/16 + 4 for the FMA chains and the butterfly).  If
+//       U < s_k - tau no row outside the rescored groups can belong to the top-k: the common case, nothing more to do.
+//       Otherwise (near-ties across more than K groups: duplicate / boilerplate chunks, or rounding at the boundary) the block
+//       scans this query's gmax column and rescoring EVERY group with gmax >= s_k - tau that was not rescored yet, then
+//       merges; the answer is then exact whatever the data.  No query is ever answered from an uncertified selection.
+template <int K, int NT>
+__global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ part_s, const int32_t* __restrict__ part_g,
+                                                      int nslices, int64_t ldg, const float* __restrict__ gmax,
+                                                      int64_t n_groups, const f16_t* __restrict__ Q,
+                                                      const f16_t* __restrict__ C, int64_t n_rows, int D, int k,
+                                                      float* __restrict__ out_s, int64_t* __restrict__ out_i,
+                                                      int64_t idx_base, float tau_scale, int debug_drop,
+                                                      unsigned long long* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int R1 = (256 * K + RS_NT - 1) / RS_NT;        // candidates per lane in stage (1): nslices <= 256
-    constexpr int KK = K > KMAX ? K : KMAX;
-    __shared__ float w_s[RS_NW][KK];
-    __shared__ int64_t w_i[RS_NW][KK];
+    constexpr int NW = NT / 64;
+    constexpr int K1 = K + 1;
+    constexpr int R1 = (256 * K + NT - 1) / NT;              // candidates per lane in stage (1): nslices <= 256
+    constexpr int KK = K1 > KMAX ? K1 : KMAX;
+    static_assert(3 * K >= NW, "fallback scratch: one 64-float row per wave inside the score + id buffers (K*64*12 bytes)");
+    __shared__ float w_s[NW][KK];
+    __shared__ int64_t w_i[NW][KK];
     __shared__ int32_t sel_g[K];
+    __shared__ float w_vb[NW];
+    __shared__ float sh_u, sh_thr, sh_qn;
+    __shared__ int sh_flag;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     f16_t* qs = reinterpret_cast<f16_t*>(smem);               // [D] query row
     float* gs = reinterpret_cast<float*>(smem + (((size_t)D * 2 + 15) & ~(size_t)15));          // [K*64] row scores
     int64_t* gi_ = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(gs) + K * GROUP_ROWS * 4);  // [K*64] row ids
-    for (int i = tid; i < (D >> 3); i += RS_NT)
+    for (int i = tid; i < (D >> 3); i += NT)
         reinterpret_cast<u32x4*>(qs)[i] = reinterpret_cast<const u32x4*>(Q + (int64_t)q * D)[i];
-    // (1) partial super-groups -> K best
+    // (1) partial super-groups -> K best (+ the best one left out)
     {
         const int ncand = nslices * K;
         float s[R1]; int64_t id[R1];
+        float vb = -INFINITY;
 #pragma unroll
         for (int j = 0; j < R1; ++j) {
             const int i = (w * R1 + j) * 64 + lane;            // wave w owns a contiguous range
@@ -201,22 +254,29 @@ __global__ __launch_bounds__(RS_NT) void rescore_kernel(const float* __restrict_
                 const int sl = i / K, p = i - sl * K;
                 const int64_t o = ((int64_t)sl * ldg + q) * K + p;
                 s[j] = part_s[o]; id[j] = part_g[o];
+                if (p == K - 1 && id[j] >= 0) vb = fmaxf(vb, s[j]);     // whatever this slice dropped scores <= its K-th kept value
             }
         }
-        wave_topk<R1>(s, id, K, lane, w_s[w], w_i[w]);
+        wave_topk<R1>(s, id, K1, lane, w_s[w], w_i[w]);
+        vb = wave_max(vb);
+        if (lane == 0) w_vb[w] = vb;
     }
     __syncthreads();
     if (w == 0) {
-        constexpr int R2 = (RS_NW * K + 63) / 64;
+        constexpr int R2 = (NW * K1 + 63) / 64;
         float s[R2]; int64_t id[R2];
 #pragma unroll
         for (int j = 0; j < R2; ++j) {
             const int i = j * 64 + lane;
-            s[j] = i < RS_NW * K ? w_s[i / K][i % K] : -INFINITY;
-            id[j] = i < RS_NW * K ? w_i[i / K][i % K] : -1;
+            s[j] = i < NW * K1 ? w_s[i / K1][i % K1] : -INFINITY;
+            id[j] = i < NW * K1 ? w_i[i / K1][i % K1] : -1;
         }
-        wave_topk<R2>(s, id, K, lane, gs, gi_);                // K best super-groups -> gs/gi_[0..K)
-        // (2) expand to K*SUPER groups, reduce to the K best groups
+        wave_topk<R2>(s, id, K1, lane, gs, gi_);               // K best super-groups -> gs/gi_[0..K), best left out -> [K]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float u = gi_[K] >= 0 ? gs[K] : -INFINITY;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) u = fmaxf(u, w_vb[ww]);
+        // (2) expand to K*SUPER groups, reduce to the K best groups (+ the best one left out)
         constexpr int R3 = (K * SUPER + 63) / 64;
         float s3[R3]; int64_t id3[R3];
 #pragma unroll
@@ -229,53 +289,32 @@ __global__ __launch_bounds__(RS_NT) void rescore_kernel(const float* __restrict_
                 if (sg >= 0 && g < n_groups) { s3[j] = gmax[g * ldg + q]; id3[j] = g; }
             }
         }
-        wave_topk<R3>(s3, id3, K, lane, w_s[0], w_i[0]);
-        if (lane < K) sel_g[lane] = (int32_t)w_i[0][lane];
+        wave_topk<R3>(s3, id3, K1, lane, w_s[0], w_i[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (w_i[0][K] >= 0) u = fmaxf(u, w_s[0][K]);
+        // test hook (ARX_TOPK_DEBUG_DROP): forget the best group, as if selection had missed it; the certificate must recover it
+        if (debug_drop && w_i[0][0] >= 0) u = fmaxf(u, w_s[0][0]);
+        if (lane < K) sel_g[lane] = !debug_drop ? (int32_t)w_i[0][lane] : (lane + 1 < K ? (int32_t)w_i[0][lane + 1] : -1);
+        // |q|_2 for the certificate's tolerance
+        float qq = 0.f;
+        for (int i = lane; i < D; i += 64) { const float v = (float)qs[i]; qq = fmaf(v, v, qq); }
+        qq = wave_sum(qq);
+        if (lane == 0) { sh_u = u; sh_qn = sqrtf(qq); }
     }
     __syncthreads();
     // (3) exact scores: 8 lanes per corpus row, 8 rows per step, several independent 16-B loads in flight per lane
     const int nch = D >> 3, l8 = lane & 7, rsub = lane >> 3;
-    constexpr int GPW = (K + RS_NW - 1) / RS_NW;              // groups per wave
+    constexpr int GPW = (K + NW - 1) / NW;                    // groups per wave
 #pragma unroll
     for (int gq = 0; gq < GPW; ++gq) {
-        const int gidx = w + gq * RS_NW;
+        const int gidx = w + gq * NW;
         if (gidx >= K) continue;
         const int gsel = sel_g[gidx];
         for (int r8 = 0; r8 < GROUP_ROWS; r8 += 8) {
             const int rr = r8 + rsub;
             const int64_t row = (int64_t)gsel * GROUP_ROWS + rr;
             const bool ok = gsel >= 0 && row < n_rows;
-            float a0 = 0.f, a1 = 0.f;
-            if (ok) {
-                const f16_t* crow = C + row * D;
-                int ch = l8;
-#pragma unroll 1
-                for (; ch + 24 < nch; ch += 32) {
-                    f16x8 cv[4], qq[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) cv[u] = *reinterpret_cast<const f16x8*>(crow + (ch + 8 * u) * 8);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) qq[u] = *reinterpret_cast<const f16x8*>(qs + (ch + 8 * u) * 8);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int e = 0; e < 8; e += 2) {
-                            a0 = fmaf((float)cv[u][e], (float)qq[u][e], a0);
-                            a1 = fmaf((float)cv[u][e + 1], (float)qq[u][e + 1], a1);
-                        }
-                }
-                for (; ch < nch; ch += 8) {
-                    const f16x8 cv = *reinterpret_cast<const f16x8*>(crow + ch * 8);
-                    const f16x8 qq = *reinterpret_cast<const f16x8*>(qs + ch * 8);
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        a0 = fmaf((float)cv[e], (float)qq[e], a0);
-                        a1 = fmaf((float)cv[e + 1], (float)qq[e + 1], a1);
-                    }
-                }
-            }
-            float a = a0 + a1;
-            a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
+            const float a = exact_row_score(C + row * D, qs, nch, l8, ok);
             if (l8 == 0) { gs[gidx * GROUP_ROWS + rr] = ok ? a : -INFINITY; gi_[gidx * GROUP_ROWS + rr] = ok ? row : -1; }
         }
     }
@@ -285,28 +324,93 @@ __global__ __launch_bounds__(RS_NT) void rescore_kernel(const float* __restrict_
         float s[GPW]; int64_t id[GPW];
 #pragma unroll
         for (int gq = 0; gq < GPW; ++gq) {
-            const int gidx = w + gq * RS_NW;
+            const int gidx = w + gq * NW;
             s[gq] = gidx < K ? gs[gidx * GROUP_ROWS + lane] : -INFINITY;
             id[gq] = gidx < K ? gi_[gidx * GROUP_ROWS + lane] : -1;
         }
         wave_topk<GPW>(s, id, k, lane, w_s[w], w_i[w]);
     }
     __syncthreads();
-    // (4) 16*k -> k
+    // (4) NW*k -> k, (5) certificate
     if (w == 0) {
-        constexpr int R4 = (RS_NW * KMAX + 63) / 64;
+        constexpr int R4 = (NW * KMAX + 63) / 64;
         float s[R4]; int64_t id[R4];
 #pragma unroll
         for (int j = 0; j < R4; ++j) {
             const int i = j * 64 + lane;
-            s[j] = i < RS_NW * k ? w_s[i / k][i % k] : -INFINITY;
-            id[j] = i < RS_NW * k ? w_i[i / k][i % k] : -1;
+            s[j] = i < NW * k ? w_s[i / k][i % k] : -INFINITY;
+            id[j] = i < NW * k ? w_i[i / k][i % k] : -1;
         }
         wave_topk<R4>(s, id, k, lane, gs, gi_);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const bool full = gi_[k - 1] >= 0;                    // k rows found
+        const float thr = full ? gs[k - 1] - tau_scale * sh_qn : -INFINITY;
+        const bool flag = sh_u > -INFINITY && sh_u >= thr;     // something unscored might belong to the top-k
+        if (lane == 0) { sh_flag = flag ? 1 : 0; sh_thr = thr; }
+        if (!flag && lane < k) {
+            out_s[(int64_t)q * k + lane] = gs[lane];
+            out_i[(int64_t)q * k + lane] = gi_[lane] >= 0 ? gi_[lane] + idx_base : -1;
+        }
+    }
+    __syncthreads();
+    if (!sh_flag) return;                                       // block-uniform
+
+    // ---- certificate fallback: rescoring every unscored group whose pass-A maximum reaches the threshold -----------------
+    float cs = -INFINITY; int64_t ci = -1;                      // this wave's running top-k: entry `lane` (lanes >= k empty)
+    if (w == 0 && lane < k) { cs = gs[lane]; ci = gi_[lane]; }
+    __syncthreads();                                            // gs is scratch from here: one 64-float row per wave
+    float* sc = gs + w * GROUP_ROWS;
+    const float thr = sh_thr;
+    unsigned long long extra = 0;
+    for (int64_t g0 = (int64_t)w * 64; g0 < n_groups; g0 += (int64_t)NW * 64) {
+        const int64_t g = g0 + lane;
+        bool sus = g < n_groups && gmax[(g < n_groups ? g : 0) * ldg + q] >= thr;
+#pragma unroll 4
+        for (int j = 0; j < K; ++j) sus = sus && (sel_g[j] != (int32_t)g);
+        unsigned long long mask = __ballot(sus);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int64_t gsel = g0 + b;
+            ++extra;
+            for (int r8 = 0; r8 < GROUP_ROWS; r8 += 8) {
+                const int rr = r8 + rsub;
+                const int64_t row = gsel * GROUP_ROWS + rr;
+                const bool ok = row < n_rows;
+                const float a = exact_row_score(C + row * D, qs, nch, l8, ok);
+                if (l8 == 0) sc[rr] = ok ? a : -INFINITY;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int64_t row = gsel * GROUP_ROWS + lane;
+            float s2[2] = {cs, sc[lane]};
+            int64_t i2[2] = {ci, row < n_rows ? row : -1};
+            wave_topk<2>(s2, i2, k, lane, w_s[w], w_i[w]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cs = lane < k ? w_s[w][lane] : -INFINITY;
+            ci = lane < k ? w_i[w][lane] : -1;
+        }
+    }
+    if (lane < k) { w_s[w][lane] = cs; w_i[w][lane] = ci; }
+    __syncthreads();
+    if (w == 0) {
+        constexpr int R4 = (NW * KMAX + 63) / 64;
+        float s[R4]; int64_t id[R4];
+#pragma unroll
+        for (int j = 0; j < R4; ++j) {
+            const int i = j * 64 + lane;
+            s[j] = i < NW * k ? w_s[i / k][i % k] : -INFINITY;
+            id[j] = i < NW * k ? w_i[i / k][i % k] : -1;
+        }
+        wave_topk<R4>(s, id, k, lane, gs, gi_);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane < k) {
             out_s[(int64_t)q * k + lane] = gs[lane];
             out_i[(int64_t)q * k + lane] = gi_[lane] >= 0 ? gi_[lane] + idx_base : -1;
         }
+    }
+    if (stats && lane == 0) {
+        if (w == 0) atomicAdd(&stats[0], 1ull);
+        if (extra) atomicAdd(&stats[1], extra);
     }
 }
 
@@ -374,7 +478,7 @@ __global__ __launch_bounds__(256) void fill_unit_rows_kernel(f16_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct TopkWs { int64_t gmax, part_s, part_g, total; int64_t ldg; int nsplit; int64_t n_groups; };
+struct TopkWs { int64_t stats, gmax, part_s, part_g, total; int64_t ldg; int nsplit; int64_t n_groups; };
 static TopkWs topk_layout(int64_t n_rows, int nq, int k) {
     TopkWs w;
     const int qb = nq < QBATCH_MAX ? nq : QBATCH_MAX;
@@ -385,6 +489,7 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k) {
     w.nsplit = (int)(ns < 1 ? 1 : (ns > 256 ? 256 : ns));
     int64_t o = 0;
     auto take = [&](int64_t b) { int64_t r = o; o += round_up64(b, 256); return r; };
+    w.stats = take(16);                                          // certificate counters, at the allocation's start (zeroed per call)
     w.gmax = take(w.n_groups * w.ldg * 4);
     w.part_s = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
     w.part_g = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
@@ -402,11 +507,7 @@ static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_row
     using ML = GemmMainloop<f16_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
     auto kern = search_groupmax_kernel<BM, GLDS>;
     constexpr int smem_bytes = (BM == 256 && GLDS) ? Gemm8Phase<f16_t, 2>::STAGE_OFF : ML::SMEM_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes));
-        attr_set = true;
-    }
+    ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem_bytes));
     const int tq = cdiv(nq, BM);
     const int64_t tn = (n_rows + 255) / 256;
     ARX_REQUIRE(tq * tn < (1ll << 31), "grid too large");
@@ -415,9 +516,9 @@ static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_row
     return ARX_OK;
 }
 
-template <int K>
+template <int K, int NT>
 static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D,
-                              int k, float* out_s, int64_t* out_i, int64_t idx_base, hipStream_t st) {
+                              int k, float* out_s, int64_t* out_i, int64_t idx_base, float tau_scale, int debug_drop, hipStream_t st) {
     float* gmax = (float*)(ws + L.gmax);
     float* ps = (float*)(ws + L.part_s);
     int32_t* pg = (int32_t*)(ws + L.part_g);
@@ -425,25 +526,18 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
         dim3 grid(cdiv(nq, 64), L.nsplit);
         const int smem_sel = SEL_SPLIT_WAVES * K * 64 * 8;
         auto ksel = select_groups_kernel<K>;
-        static bool sel_attr = false;
-        if (!sel_attr && smem_sel > 48 * 1024) {
-            ARX_HIP_CHECK(hipFuncSetAttribute((const void*)ksel, hipFuncAttributeMaxDynamicSharedMemorySize, smem_sel));
-            sel_attr = true;
-        }
+        if (smem_sel > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)ksel, smem_sel));
         ProfScope psc(ARX_K_SEARCH_SELECT, st);
         ksel<<<grid, 256, smem_sel, st>>>(gmax, L.ldg, (L.n_groups + SUPER - 1) / SUPER, L.n_groups, nq, L.nsplit, ps, pg);
         ARX_HIP_CHECK(hipGetLastError());
     }
     const int nslices = L.nsplit;
     const size_t smem = (((size_t)D * 2 + 15) & ~(size_t)15) + (size_t)K * GROUP_ROWS * 12;
-    auto kern = rescore_kernel<K>;
-    static size_t attr_max = 0;
-    if (smem > 48 * 1024 && smem > attr_max) {
-        ARX_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_max = smem;
-    }
+    auto kern = rescore_kernel<K, NT>;
+    if (smem > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)kern, (int)smem));
     ProfScope psc(ARX_K_SEARCH_RESCORE, st);
-    kern<<<nq, RS_NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base);
+    kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
+                               debug_drop, (unsigned long long*)(ws + L.stats));
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -459,8 +553,18 @@ extern "C" int32_t arx_topk_search(const void* corpus, int64_t n_rows, const voi
     ARX_REQUIRE(ws_bytes >= L.total, "workspace too small: %lld < %lld", (long long)ws_bytes, (long long)L.total);
     hipStream_t st = (hipStream_t)stream;
     const f16_t* C = (const f16_t*)corpus;
+#ifdef ARX_DEV_VARIANTS
     const char* genv = getenv("ARX_GEMM_GLDS");
     const bool glds = !(genv && genv[0] == '0');
+#endif
+    // certificate tolerance (rescore_kernel step 5): eps_A + eps_B per unit of |q|_2, corpus rows of norm <= 1 + 2^-9
+    float tau_scale = (0.3125f * (float)dim + 4.0f) * 5.9604645e-8f * (1.0f + 1.0f / 512.0f);
+    if (const char* te = getenv("ARX_TOPK_TAU_SCALE")) tau_scale *= (float)atof(te);      // test hook: > 1 widens the net (1e9 = rescoring everything)
+    const char* de = getenv("ARX_TOPK_DEBUG_DROP");                                       // test hook: selection forgets the best group
+    const int debug_drop = (de && de[0] == '1') ? 1 : 0;
+    const char* re = getenv("ARX_TOPK_RS");                                               // dev A/B: rescore geometry
+    const int rs = re ? atoi(re) : 0;
+    ARX_HIP_CHECK(hipMemsetAsync((char*)ws + L.stats, 0, 16, st));
     for (int q0 = 0; q0 < n_queries; q0 += QBATCH_MAX) {
         const int nq = (n_queries - q0) < QBATCH_MAX ? (n_queries - q0) : QBATCH_MAX;
         const f16_t* Q = (const f16_t*)queries + (int64_t)q0 * dim;
@@ -468,23 +572,36 @@ extern "C" int32_t arx_topk_search(const void* corpus, int64_t n_rows, const voi
         int rc;
         {
         ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
-        if (glds) {
-            rc = nq <= 64 ? launch_groupmax<64, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
-               : nq <= 128 ? launch_groupmax<128, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
-                           : launch_groupmax<256, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st);
-        } else {
+#ifdef ARX_DEV_VARIANTS
+        if (!glds) {
             rc = nq <= 64 ? launch_groupmax<64, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
                : nq <= 128 ? launch_groupmax<128, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
                            : launch_groupmax<256, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, st);
-        }
+        } else
+#endif
+            rc = nq <= 64 ? launch_groupmax<64, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
+               : nq <= 128 ? launch_groupmax<128, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
+                           : launch_groupmax<256, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st);
         }
         if (rc != ARX_OK) return rc;
         float* os = out_scores + (int64_t)q0 * k;
         int64_t* oi = out_ids + (int64_t)q0 * k;
-        if (k <= 10) rc = run_select_rescore<KSEL_SMALL>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, st);
-        else rc = run_select_rescore<KSEL_BIG>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, st);
+        if (k > 10) rc = run_select_rescore<KSEL_BIG, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
+        else if (rs == 1) rc = run_select_rescore<16, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
+        else if (rs == 2) rc = run_select_rescore<16, 256>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
+        else if (rs == 3) rc = run_select_rescore<12, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
+        else rc = run_select_rescore<KSEL_SMALL, 256>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
         if (rc != ARX_OK) return rc;
     }
+    return ARX_OK;
+}
+
+extern "C" int32_t arx_topk_stats(const void* ws, int64_t* flagged_queries, int64_t* extra_groups, void* stream) {
+    ARX_REQUIRE(ws && flagged_queries && extra_groups, "null pointer argument");
+    unsigned long long h[2] = {0, 0};
+    ARX_HIP_CHECK(hipMemcpyAsync(h, ws, 16, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ARX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    *flagged_queries = (int64_t)h[0]; *extra_groups = (int64_t)h[1];
     return ARX_OK;
 }
 

@@ -162,35 +162,49 @@ class HipEncoder:
         return ids, lens
 
     def encode_ragged(self, seqs: Sequence[Sequence[int]], batch_size: int = 256, normalize: bool = True,
-                      on_device: bool = False):
+                      on_device: bool = False, out_f16: Optional[torch.Tensor] = None):
         """Token-id lists -> f32 [n, H] numpy, input order preserved.  Sorted by length (descending, as
         sentence-transformers does) so each forward pads to a similar length; results do not depend on
         batch composition (key-padding mask), so the re-bucketing is invisible to the caller.  All forwards of the
         call are queued on the stream and the rows come back with ONE device->host copy (`on_device=True`: no copy,
-        a device tensor in input order, for a consumer that also lives on the GPU)."""
+        a device tensor in input order, for a consumer that also lives on the GPU).  `out_f16` (device fp16 [n, >= H], e.g. a
+        slice of the rank's corpus shard) additionally receives the kernel's own fp16 rows, in input order: the shard is filled
+        where it will be searched and never crosses PCIe."""
         n = len(seqs)
         if n == 0:
             return (torch.zeros((0, self.cfg.hidden), dtype=torch.float32, device=self.device) if on_device
                     else np.zeros((0, self.cfg.hidden), np.float32))
         order = sorted(range(n), key=lambda i: -len(seqs[i]))
         dev_out = torch.empty((n, self.cfg.hidden), dtype=torch.float32, device=self.device)
+        dev16 = self._f16_stage(n, out_f16)
         for s0 in range(0, n, batch_size):
             idx = order[s0:s0 + batch_size]
             ids, lens = self._pad_batch(seqs, idx, self.cfg.pad_id)
             d_ids = torch.from_numpy(ids).to(self.device, non_blocking=True)
             d_lens = torch.from_numpy(lens).to(self.device, non_blocking=True)
             self.forward_tokens(d_ids, d_lens, ids.shape[1], max(int(lens.sum()), 1), out=dev_out[s0:s0 + len(idx)],
-                                normalize=normalize)
+                                out_f16=None if dev16 is None else dev16[s0:s0 + len(idx)], normalize=normalize)
+        order_t = torch.as_tensor(order, device=self.device) if (on_device or dev16 is not None) else None
+        if dev16 is not None:
+            out_f16[:, :self.cfg.hidden].index_copy_(0, order_t, dev16)
         if on_device:
             out = torch.empty_like(dev_out)
-            out[torch.as_tensor(order, device=self.device)] = dev_out
+            out[order_t] = dev_out
             return out
         out = np.empty((n, self.cfg.hidden), np.float32)
         out[np.asarray(order)] = dev_out.cpu().numpy()
         return out
 
+    def _f16_stage(self, n: int, out_f16: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """Length-sorted staging rows for the fp16 output (the forwards write sorted order; one index_copy un-sorts)."""
+        if out_f16 is None:
+            return None
+        assert out_f16.is_cuda and out_f16.dtype == torch.float16 and out_f16.dim() == 2 and out_f16.stride(1) == 1
+        assert out_f16.shape[0] == n and out_f16.shape[1] >= self.cfg.hidden, "out_f16 must be [n, >= hidden]"
+        return torch.empty((n, self.cfg.hidden), dtype=torch.float16, device=self.device)
+
     def encode_packed(self, ids: np.ndarray, lens: np.ndarray, batch_size: int = 256, normalize: bool = True,
-                      on_device: bool = False):
+                      on_device: bool = False, out_f16: Optional[torch.Tensor] = None):
         """`encode_ragged` for a tokenizer that already produced a right-padded id matrix (int32 [n, W]) and lengths: no
         per-token Python objects anywhere on the host path.  Same length-sorted batching, same rows."""
         n = int(len(lens))
@@ -200,16 +214,21 @@ class HipEncoder:
         lens = np.ascontiguousarray(lens, dtype=np.int32)
         order = np.argsort(-lens.astype(np.int64), kind="stable")
         dev_out = torch.empty((n, self.cfg.hidden), dtype=torch.float32, device=self.device)
+        dev16 = self._f16_stage(n, out_f16)
         for s0 in range(0, n, batch_size):
             idx = order[s0:s0 + batch_size]
             bl = lens[idx]
             ml = max(int(bl.max()), 1)
             d_ids = torch.from_numpy(np.ascontiguousarray(ids[idx, :ml], dtype=np.int32)).to(self.device, non_blocking=True)
             d_lens = torch.from_numpy(np.ascontiguousarray(bl)).to(self.device, non_blocking=True)
-            self.forward_tokens(d_ids, d_lens, ml, max(int(bl.sum()), 1), out=dev_out[s0:s0 + len(idx)], normalize=normalize)
+            self.forward_tokens(d_ids, d_lens, ml, max(int(bl.sum()), 1), out=dev_out[s0:s0 + len(idx)],
+                                out_f16=None if dev16 is None else dev16[s0:s0 + len(idx)], normalize=normalize)
+        order_t = torch.from_numpy(order).to(self.device) if (on_device or dev16 is not None) else None
+        if dev16 is not None:
+            out_f16[:, :self.cfg.hidden].index_copy_(0, order_t, dev16)
         if on_device:
             out = torch.empty_like(dev_out)
-            out[torch.from_numpy(order).to(self.device)] = dev_out
+            out[order_t] = dev_out
             return out
         out = np.empty((n, self.cfg.hidden), np.float32)
         out[order] = dev_out.cpu().numpy()
@@ -273,10 +292,11 @@ class HipSentenceEncoder:
             return ("packed", ids, lens)
         return ("ragged", self.tokenize(sentences))
 
-    def _encode_tokens_any(self, toks, bs: int, normalize: bool, on_device: bool = False):
+    def _encode_tokens_any(self, toks, bs: int, normalize: bool, on_device: bool = False, out_f16=None):
         if toks[0] == "packed":
-            return self.encoder.encode_packed(toks[1], toks[2], batch_size=bs, normalize=normalize, on_device=on_device)
-        return self.encoder.encode_ragged(toks[1], batch_size=bs, normalize=normalize, on_device=on_device)
+            return self.encoder.encode_packed(toks[1], toks[2], batch_size=bs, normalize=normalize, on_device=on_device,
+                                              out_f16=out_f16)
+        return self.encoder.encode_ragged(toks[1], batch_size=bs, normalize=normalize, on_device=on_device, out_f16=out_f16)
 
     def encode_device(self, sentences: Sequence[str], batch_size: int = 32, normalize_embeddings: bool = False) -> torch.Tensor:
         """Rows stay in HBM (f32 [n, D], input order) — for GPU-side consumers (adjacent cosine, the search index)."""
@@ -284,7 +304,10 @@ class HipSentenceEncoder:
         return self._encode_tokens_any(self._tokenize_any(list(sentences)), bs, normalize_embeddings, on_device=True)
 
     def encode(self, sentences, batch_size: int = 32, show_progress_bar=None, convert_to_numpy: bool = True,
-               convert_to_tensor: bool = False, normalize_embeddings: bool = False, **_ignored):
+               convert_to_tensor: bool = False, normalize_embeddings: bool = False, device_f16_out: Optional[torch.Tensor] = None,
+               **_ignored):
+        """`device_f16_out` (additive; device fp16 [n, >= D]): the same rows, as the kernel's own fp16 output, are also left in
+        HBM in input order — the CLI passes a slice of the rank's corpus shard, so the search step never re-uploads them."""
         single = isinstance(sentences, str)
         if single:
             sentences = [sentences]
@@ -293,7 +316,7 @@ class HipSentenceEncoder:
         slab = max(bs, self.slab_texts)
         first = max(bs, self.first_slab_texts)
         if len(sentences) <= first:
-            emb = self._encode_tokens_any(self._tokenize_any(sentences), bs, normalize_embeddings)
+            emb = self._encode_tokens_any(self._tokenize_any(sentences), bs, normalize_embeddings, out_f16=device_f16_out)
         else:
             # feeder: the tokenizer (native C++ or Rust; both release the GIL) works on slab i+1 in a helper thread while the GPU encodes slab i;
             # slabs grow 1024, 2048, ... up to slab_texts so the GPU starts after ~25 ms of tokenisation, not a whole slab
@@ -310,7 +333,8 @@ class HipSentenceEncoder:
                     seqs = fut.result()
                     if bi + 1 < len(bounds):
                         fut = ex.submit(self._tokenize_any, sentences[bounds[bi + 1][0]:bounds[bi + 1][1]])
-                    parts.append(self._encode_tokens_any(seqs, bs, normalize_embeddings))
+                    o16 = None if device_f16_out is None else device_f16_out[bounds[bi][0]:bounds[bi][1]]
+                    parts.append(self._encode_tokens_any(seqs, bs, normalize_embeddings, out_f16=o16))
             emb = np.concatenate(parts, 0)
         if convert_to_tensor:
             emb = torch.from_numpy(emb)

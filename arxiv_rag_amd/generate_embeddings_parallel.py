@@ -70,19 +70,41 @@ def load_chunks_from_file(file_path: Path, min_quality: float = 0.8) -> List[Dic
     return kept
 
 
+def _load_many(args: Tuple[List[str], float]) -> List[Dict]:
+    paths, min_quality = args
+    out: List[Dict] = []
+    for p in paths:
+        out.extend(load_chunks_from_file(Path(p), min_quality))
+    return out
+
+
+PROCESS_POOL_MIN_FILES = 4096      # below this a spawn pool's start-up (~0.2 s per worker) costs more than it saves
+
+
 def load_chunks_parallel(output_dir: Path, min_quality: float = 0.8, num_workers: Optional[int] = None) -> List[Dict]:
     """All `*.json` under the tree except `._*` (GEN:94-129).  Files are visited in SORTED order and
     results concatenated in that order: the reference's imap_unordered order is not a contract, and a
-    deterministic order is what lets N ranks agree on the shard boundaries."""
+    deterministic order is what lets N ranks agree on the shard boundaries.  `json.load` holds the GIL, so a corpus-sized
+    tree (GEN:103 sizes its pool for 70 k files) is parsed by a process pool — `spawn` context, as GEN:611-616 sets, which is
+    also the only start method that is safe once the process has touched the GPU — fed contiguous slices of the sorted
+    list through ordered `imap`; small trees are read by a thread pool in-process."""
     files = sorted(f for f in Path(output_dir).rglob("*.json") if not f.name.startswith("._"))
     if num_workers is None:
         num_workers = max(1, int(mp.cpu_count() * 0.8))
     print(f"Loading chunks from {len(files):,} files using {num_workers} workers...")
     out: List[Dict] = []
-    with ThreadPoolExecutor(max_workers=min(num_workers, 64)) as ex:
-        for part in ex.map(lambda f: load_chunks_from_file(f, min_quality), files):
-            if part:
+    if len(files) >= PROCESS_POOL_MIN_FILES and num_workers > 1:
+        nproc = min(num_workers, 64, max(2, len(files) // 1024))
+        step = 128
+        jobs = [([str(f) for f in files[i:i + step]], min_quality) for i in range(0, len(files), step)]
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            for part in pool.imap(_load_many, jobs, chunksize=1):
                 out.extend(part)
+    else:
+        with ThreadPoolExecutor(max_workers=min(num_workers, 64)) as ex:
+            for part in ex.map(lambda f: load_chunks_from_file(f, min_quality), files):
+                if part:
+                    out.extend(part)
     print(f"Loaded {len(out):,} high-quality chunks (quality >= {min_quality})")
     return out
 
@@ -117,8 +139,39 @@ def generate_embeddings_worker(args: Tuple[List[str], str, int, int]) -> Tuple[i
         return (batch_idx, [], msg)
 
 
+class ShardSink:
+    """This rank's fp16 corpus shard, resident in HBM: rows [lo, hi) of the corpus, filled by the encoder kernels while the
+    chunks are being embedded (`encode(..., device_f16_out=...)`) and searched where they lie — corpus rows never cross PCIe
+    towards the device.  Only rows that came out of the reference's fallback policy (per-item retry / zero rows, GEN:155-169;
+    host arrays by construction) are uploaded, a quantum at a time."""
+
+    def __init__(self, model, lo: int, hi: int):
+        import torch
+        self.lo, self.hi = lo, hi
+        self.rows = torch.zeros((hi - lo, model.get_sentence_embedding_dimension()), dtype=torch.float16,
+                                device=model.encoder.device)
+
+    def view(self, a: int, b: int):
+        return self.rows[a - self.lo:b - self.lo]
+
+    def put(self, a: int, rows: Sequence[np.ndarray]):
+        import torch
+        if len(rows):
+            host = np.asarray(rows, dtype=np.float32).astype(np.float16)
+            self.rows[a - self.lo:a - self.lo + len(rows)] = torch.from_numpy(host).to(self.rows.device)
+
+
+def make_shard_sink(model, n_texts: int, chunks_per_worker: int, world: int, rank: int) -> Optional["ShardSink"]:
+    """A sink for the row range this rank encodes (same split as the dispatchers below); None for a model with no device."""
+    if getattr(model, "encoder", None) is None or not hasattr(model.encoder, "device"):
+        return None
+    n_quanta = (n_texts + chunks_per_worker - 1) // chunks_per_worker
+    q_lo, q_hi = (0, n_quanta) if world == 1 else shard_range(n_quanta, world, rank)
+    return ShardSink(model, min(n_texts, q_lo * chunks_per_worker), min(n_texts, q_hi * chunks_per_worker))
+
+
 def _encode_quanta(texts: List[str], q_lo: int, q_hi: int, model_name: str, batch_size: int, chunks_per_worker: int,
-                   super_quanta: int = 32):
+                   super_quanta: int = 32, sink: Optional[ShardSink] = None):
     """Quanta [q_lo, q_hi) -> yields (qi, rows, err) exactly as `generate_embeddings_worker` would, but fast: a HIP sentence
     encoder gets `super_quanta` quanta per `encode()` call (rows do not depend on how texts are batched, so the result is the same;
     the tokenizer feeder and the 1024-sequence forwards then run at the device-bound rate instead of 200 texts at a time).  Any
@@ -137,8 +190,9 @@ def _encode_quanta(texts: List[str], q_lo: int, q_hi: int, model_name: str, batc
         rows = None
         if fast:
             try:
+                extra = {"device_f16_out": sink.view(a, b)} if sink is not None else {}
                 rows = model.encode(texts[a:b], batch_size=batch_size, normalize_embeddings=True, show_progress_bar=False,
-                                    convert_to_numpy=True, convert_to_tensor=False)
+                                    convert_to_numpy=True, convert_to_tensor=False, **extra)
                 if len(rows) != b - a:
                     rows = None
             except Exception:
@@ -148,7 +202,14 @@ def _encode_quanta(texts: List[str], q_lo: int, q_hi: int, model_name: str, batc
             if rows is not None:
                 yield (q, list(rows[qa - a:qb - a]), None)
             else:
-                yield generate_embeddings_worker((texts[qa:qb], model_name, batch_size, q))
+                res = generate_embeddings_worker((texts[qa:qb], model_name, batch_size, q))
+                if sink is not None:                     # fallback rows are host arrays: this quantum's shard rows are replaced
+                    try:
+                        sink.view(qa, qb).zero_()
+                        sink.put(qa, res[1][:qb - qa])
+                    except Exception:                    # noqa: BLE001  (never raise per chunk; the rows stay zero)
+                        pass
+                yield res
         qi = qe
 
 
@@ -164,7 +225,8 @@ def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 def generate_embeddings_parallel(chunks: List[Dict], model_name: str = "all-mpnet-base-v2", batch_size: int = 200,
-                                 num_workers: Optional[int] = None, chunks_per_worker: int = 500) -> List[np.ndarray]:
+                                 num_workers: Optional[int] = None, chunks_per_worker: int = 500,
+                                 sink: Optional[ShardSink] = None) -> List[np.ndarray]:
     """Embedding i <-> chunk i (GEN:179-269).  Quanta of chunks_per_worker texts; with torchrun each rank takes
     a contiguous range of quanta and the per-rank results are exchanged so every rank returns all N rows
     (missing quanta -> zero rows, count mismatch -> pad/truncate, as GEN:260-267)."""
@@ -179,7 +241,7 @@ def generate_embeddings_parallel(chunks: List[Dict], model_name: str = "all-mpne
     q_lo, q_hi = shard_range(len(quanta), world, rank)
     done: Dict[int, List[np.ndarray]] = {}
     errors: List[str] = []
-    for idx, rows, err in _encode_quanta(texts, q_lo, q_hi, model_name, batch_size, chunks_per_worker):
+    for idx, rows, err in _encode_quanta(texts, q_lo, q_hi, model_name, batch_size, chunks_per_worker, sink=sink):
         if err:
             errors.append(f"Batch {idx}: {err}")
         if rows:
@@ -218,7 +280,7 @@ def generate_embeddings_parallel(chunks: List[Dict], model_name: str = "all-mpne
 
 
 def generate_embeddings_sharded(chunks: List[Dict], model_name: str, batch_size: int = 200,
-                                chunks_per_worker: int = 500) -> Tuple[np.ndarray, int, int]:
+                                chunks_per_worker: int = 500, sink: Optional[ShardSink] = None) -> Tuple[np.ndarray, int, int]:
     """Multi-rank form of the dispatcher: this rank encodes a contiguous range of quanta and KEEPS its rows
     (no exchange of embeddings: at ~5 M chunks x 768 that would be 15 GB per rank for nothing).
     Returns (rows float32 [hi-lo, D], lo, hi) with row j <-> chunk lo + j; failed quanta are zero rows."""
@@ -233,7 +295,7 @@ def generate_embeddings_sharded(chunks: List[Dict], model_name: str, batch_size:
     dim = get_worker_model(model_name).get_sentence_embedding_dimension()
     rows = np.zeros((hi - lo, dim), np.float32)
     errors = 0
-    for idx, got, err in _encode_quanta(texts, q_lo, q_hi, model_name, batch_size, chunks_per_worker):
+    for idx, got, err in _encode_quanta(texts, q_lo, q_hi, model_name, batch_size, chunks_per_worker, sink=sink):
         a, b = idx * chunks_per_worker, min(len(texts), (idx + 1) * chunks_per_worker)
         if err or len(got) != b - a:
             errors += 1
@@ -394,28 +456,33 @@ def store_in_chroma_batched(chunks: List[Dict], embeddings: Sequence, db_path: s
 
 
 # --------------------------------------------------------------------------------------------- search (added step)
-def search_queries(model, chunks: List[Dict], embeddings: Sequence, queries: List[str], top_k: int = 10,
+def search_queries(model, chunks: List[Dict], shard, queries: List[str], top_k: int = 10,
                    output_dir: str = "./embeddings_saved", local_range: Optional[Tuple[int, int]] = None) -> List[Dict]:
     """Brute-force cosine top-k (config.yaml:63-64 `top_k: 10`) over the rank's fp16 rows in HBM; with
     torchrun each rank holds the contiguous row shard it encoded and the partial top-k lists are
-    all-gathered over RCCL and merged."""
+    all-gathered over RCCL and merged.  `shard` is the `ShardSink` the encode step filled (rows [lo, hi) already in HBM:
+    nothing is uploaded here); a host matrix is also accepted for callers that only have the `.npy` rows (it is uploaded
+    once — `store.HipCollection` is the API meant for that)."""
     import torch
     from .index import ShardIndex, shard_bounds
     dist = _dist()
     world = dist.get_world_size() if dist else 1
     rank = dist.get_rank() if dist else 0
     dev = model.encoder.device
-    if local_range is not None:                       # `embeddings` already holds only this rank's rows [lo, hi)
-        lo, hi = local_range
-        local = embeddings
+    if isinstance(shard, ShardSink):
+        lo, rows = shard.lo, shard.rows
     else:
-        lo, hi = shard_bounds(len(embeddings), world, rank)
-        local = embeddings[lo:hi]
-    shard = torch.from_numpy(np.asarray(local, dtype=np.float16)).to(dev) if hi > lo else \
-        torch.empty((0, model.get_sentence_embedding_dimension()), dtype=torch.float16, device=dev)
-    q = model.encode(queries, batch_size=256, normalize_embeddings=True, convert_to_numpy=True)
-    qd = torch.from_numpy(np.asarray(q, dtype=np.float16)).to(dev)
-    s, i = ShardIndex(shard, idx_base=lo).search_distributed(qd, top_k)
+        if local_range is not None:                   # `shard` already holds only this rank's rows [lo, hi)
+            lo, hi = local_range
+            local = shard
+        else:
+            lo, hi = shard_bounds(len(shard), world, rank)
+            local = shard[lo:hi]
+        rows = torch.from_numpy(np.ascontiguousarray(np.asarray(local, dtype=np.float16))).to(dev) if hi > lo else \
+            torch.empty((0, model.get_sentence_embedding_dimension()), dtype=torch.float16, device=dev)
+    qd = torch.empty((len(queries), model.get_sentence_embedding_dimension()), dtype=torch.float16, device=dev)
+    model.encode(queries, batch_size=256, normalize_embeddings=True, convert_to_numpy=True, device_f16_out=qd)
+    s, i = ShardIndex(rows, idx_base=lo).search_distributed(qd, top_k)
     s, i = s.cpu().numpy(), i.cpu().numpy()
     results = []
     for qi, text in enumerate(queries):
@@ -508,13 +575,19 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
             meta_prefetch.start()
         t0 = time.time()
         local_range = None
+        qs = []
+        if args.queries:
+            qs = [ln.strip() for ln in Path(args.queries).read_text(encoding="utf-8").splitlines() if ln.strip()]
+        # the search step works on the rows where the encoder leaves them: an fp16 shard in this rank's HBM
+        sink = make_shard_sink(_model, len(chunks), args.chunks_per_worker, world, rank) if qs else None
         if world > 1:
             # one process per GPU: every rank encodes, keeps and writes its own contiguous row range
-            embeddings, lo, hi = generate_embeddings_sharded(chunks, args.model, args.batch_size, args.chunks_per_worker)
+            embeddings, lo, hi = generate_embeddings_sharded(chunks, args.model, args.batch_size, args.chunks_per_worker, sink=sink)
             local_range = (lo, hi)
         else:
             embeddings = generate_embeddings_parallel(chunks, model_name=args.model, batch_size=args.batch_size,
-                                                      num_workers=args.embedding_workers, chunks_per_worker=args.chunks_per_worker)
+                                                      num_workers=args.embedding_workers, chunks_per_worker=args.chunks_per_worker,
+                                                      sink=sink)
         embedding_time = time.time() - t0
         print(f"Embedding generation completed in {embedding_time:.1f} seconds ({embedding_time / 60:.1f} min)\n")
         if world > 1:
@@ -526,10 +599,8 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
                                              prefetch=meta_prefetch)
             print()
         meta_prefetch = None
-        if args.queries:
-            qs = [ln.strip() for ln in Path(args.queries).read_text(encoding="utf-8").splitlines() if ln.strip()]
-            if qs:
-                search_queries(_model, chunks, embeddings, qs, top_k=args.top_k, local_range=local_range)
+        if qs:
+            search_queries(_model, chunks, sink if sink is not None else embeddings, qs, top_k=args.top_k, local_range=local_range)
         store_time = 0.0
         if rank == 0 and not args.skip_chroma:
             try:

@@ -52,6 +52,18 @@ class ShardIndex:
         _lib.check(rc, "arx_topk_search")
         return scores, ids
 
+    def certificate_stats(self) -> Tuple[int, int]:
+        """(queries whose first selection could not be certified, extra 64-row groups rescored for them) of the LAST `search`
+        on this index: the answer is exact either way (csrc/search.hip, rescore_kernel step 5); the counters say how often the
+        slow path ran.  Synchronises on the current stream."""
+        import ctypes as C
+        if self._ws is None:
+            return (0, 0)
+        a, b = C.c_int64(0), C.c_int64(0)
+        _lib.check(self.lib.arx_topk_stats(self._ws.data_ptr(), C.byref(a), C.byref(b), torch.cuda.current_stream().cuda_stream),
+                   "arx_topk_stats")
+        return (int(a.value), int(b.value))
+
     def search_distributed(self, queries_f16: torch.Tensor, k: int = 10, group=None):
         """Every rank passes the SAME queries; returns the global top-k on every rank."""
         import torch.distributed as dist

@@ -84,6 +84,36 @@ def seeded_state_dict(cfg: EncoderConfig, seed: int = 0, std: float = 0.02,
     return sd
 
 
+def adversarial_state_dict(cfg: EncoderConfig, seed: int = 0, row_offset: float = 4.0) -> Dict[str, np.ndarray]:
+    """Seeded weights with the statistics trained checkpoints have and `seeded_state_dict` lacks — the regime in which a
+    LayerNorm folded into the next GEMM as rstd*(acc - mean*s) over a bf16 pre-LN stream could lose precision:
+      * LayerNorm gamma log-uniform in [0.25, 4] with two outlier channels at 10 per LayerNorm, beta ~ N(0, 0.5) with the same
+        two channels at +-5 (trained BERT/MPNet models carry a few such channels);
+      * a common offset of `row_offset` on every output-projection / FFN-2 bias, so each pre-LN row has |mean| well above its
+        standard deviation (cancellation in E[y^2] - mean^2, coarse bf16 grid at the row's magnitude);
+      * heavy-tailed matrices: Student-t (3 degrees of freedom) entries scaled to std 0.04.
+    Same construction on any box from (cfg, seed): fixtures carry only the seed."""
+    sd = seeded_state_dict(cfg, seed=seed, std=0.04, bias_std=0.02, ln_jitter=0.0)
+    rs = np.random.RandomState(seed + 777)
+    for key in list(sd):
+        shape = sd[key].shape
+        if "LayerNorm.weight" in key:
+            g = np.exp(rs.uniform(np.log(0.25), np.log(4.0), size=shape)).astype(np.float32)
+            out = rs.choice(shape[0], size=2, replace=False)
+            g[out] = 10.0
+            sd[key] = g
+            b = (rs.standard_normal(shape) * 0.5).astype(np.float32)
+            b[out] = np.array([5.0, -5.0], np.float32)
+            sd[key.replace(".weight", ".bias")] = b
+        elif key.endswith(".weight") and len(shape) == 2 and "embeddings" not in key and "relative_attention_bias" not in key:
+            sd[key] = (rs.standard_t(3, size=shape) * (0.04 / np.sqrt(3.0))).astype(np.float32)
+    for i in range(cfg.layers):
+        k = layer_keys(cfg, i)
+        for n in ("o", "fc2"):
+            sd[k[n] + ".bias"] = (sd[k[n] + ".bias"] + np.float32(row_offset)).astype(np.float32)
+    return sd
+
+
 def load_hf_dir(path: str | Path, cfg: EncoderConfig) -> Dict[str, np.ndarray]:
     """Load model.safetensors (preferred) or pytorch_model.bin (weights_only=True)
     from a local HF-layout directory; strips an optional 'mpnet.' / 'bert.' prefix."""

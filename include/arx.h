@@ -135,6 +135,12 @@ int32_t arx_topk_search(const void* corpus, int64_t n_rows, const void* queries,
                         int32_t dim, int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base,
                         void* ws, int64_t ws_bytes, void* stream);
 
+/* Exactness certificate of the LAST arx_topk_search on this workspace (csrc/search.hip, rescore_kernel step 5): the number of
+ * queries whose first selection could not be certified (an unscored 64-row group reached the k-th exact score minus the
+ * rounding tolerance) and the number of extra groups that were then rescored for them.  Every answer is exact either way; the
+ * counters say how often the slow path ran (near-duplicate chunks).  Copies 16 bytes to the host and waits on `stream`. */
+int32_t arx_topk_stats(const void* ws, int64_t* flagged_queries, int64_t* extra_groups, void* stream);
+
 /* Merge P partial top-k lists (e.g. the all-gathered per-shard results) into the global top-k.
  *   scores f32 [P, n_queries, k], ids int64 [P, n_queries, k] (device) -> out [n_queries, k]. */
 int32_t arx_topk_merge(const float* scores, const int64_t* ids, int32_t n_parts, int32_t n_queries,

@@ -28,11 +28,9 @@ def hip():
     return _lib
 
 
-@pytest.mark.parametrize("glds", ["1", "0"])
 @pytest.mark.parametrize("name", ["tiny-mpnet", "tiny-bert", "tiny-bert-cls"])
-def test_tiny_golden_all_layers(hip, golden_dir, name, glds, monkeypatch):
+def test_tiny_golden_all_layers(hip, golden_dir, name):
     from arxiv_rag_amd.encoder import HipEncoder
-    monkeypatch.setenv("ARX_GEMM_GLDS", glds)
     g = np.load(golden_dir / f"{name}.npz")
     cfg = C.PRESETS[name]
     sd = {k[2:]: g[k] for k in g.files if k.startswith("w:")}
@@ -73,8 +71,38 @@ def test_full_shape_golden(hip, golden_dir, name, key):
     seqs = [ids[r, :lens[r]].tolist() for r in range(len(lens))]
     emb2 = enc.encode_ragged(seqs, batch_size=5)
     assert _cos(emb2, ref).min() > 1 - 1e-3
-    assert _cos(emb2, emb).min() > 1 - 2e-5
+    # bitwise: token-packed activations, fixed-order row statistics and a per-(sequence, head) attention block make a row
+    # independent of what else is in the batch, of the padded width and of the forward's size
+    assert np.array_equal(emb2, emb)
+    solo = np.concatenate([enc.encode_ragged([sq]) for sq in seqs[:6]], 0)
+    assert np.array_equal(solo, emb[:6])
+    wide = np.full((len(lens), 384), cfg.pad_id, ids.dtype); wide[:, :ids.shape[1]] = ids
+    assert np.array_equal(enc.encode_tokens(wide, lens).cpu().numpy(), emb)
     enc.close()
+
+
+@pytest.mark.parametrize("fold", ["1", "0"])
+@pytest.mark.parametrize("name", ["all-mpnet-base-v2", "all-MiniLM-L6-v2", "BAAI/bge-large-en-v1.5"])
+def test_full_shape_adversarial_statistics(hip, golden_dir, name, fold, monkeypatch):
+    """The regime seeded N(0, sigma) weights never reach (VERDICT r1 / ADVICE): LayerNorm gamma log-uniform in [0.25, 4] with
+    outlier channels at 10, beta with +-5 outliers, every pre-LN row offset by 4 (|mean| >> spread: the one-pass variance
+    E[y^2] - mean^2 cancels, the bf16 pre-LN stream sits on a coarse grid), Student-t matrices.  Both the LN-fold schedule and
+    the explicit-LayerNorm schedule must hold the north-star bar against the transformers outputs in full_shapes_adv.npz."""
+    from arxiv_rag_amd.encoder import HipEncoder
+    from arxiv_rag_amd.weights import adversarial_state_dict
+    monkeypatch.setenv("ARX_LN_FOLD", fold)
+    g = np.load(golden_dir / "full_shapes_adv.npz")
+    cfg = C.PRESETS[name]
+    key = name.replace("/", "_") + ":adv"
+    seed, off = g[key + ":wspec"]
+    sd = adversarial_state_dict(cfg, seed=int(seed), row_offset=float(off))
+    ids, lens, ref = g[key + ":ids"], g[key + ":lens"], g[key + ":emb"]
+    enc = HipEncoder(cfg, sd)
+    emb = enc.encode_tokens(ids, lens).cpu().numpy()
+    enc.close()
+    c = _cos(emb, ref)
+    print(f"adversarial {name} ln_fold={fold}: worst 1-cos = {1 - c.min():.2e}")
+    assert np.isfinite(emb).all() and c.min() > 1 - 1e-3, (name, fold, 1 - c.min())
 
 
 def test_encoder_vs_oracle_random_batch(hip):
@@ -142,9 +170,7 @@ def _check_search(C_, Q_, k, idx_base=0):
     return s, i, rs[:, :k], ri[:, :k]
 
 
-@pytest.mark.parametrize("glds", ["1", "0"])
-def test_search_golden_with_exact_ties(hip, golden_dir, glds, monkeypatch):
-    monkeypatch.setenv("ARX_GEMM_GLDS", glds)
+def test_search_golden_with_exact_ties(hip, golden_dir):
     g = np.load(golden_dir / "search_4096x768.npz")
     Cm = SO.unit_rows_f16(4096, 768, 7); Q = SO.unit_rows_f16(64, 768, 11)
     Cm[100] = Cm[17]; Cm[2000] = Cm[17]; Cm[3000] = Cm[17]; Q[0] = Cm[17]
@@ -168,6 +194,72 @@ def test_search_duplicate_rows_everywhere(hip):
     Z = np.zeros((500, 128), np.float16)
     s, i, _, _ = _check_search(Z, Q, 10)
     assert np.array_equal(i, np.tile(np.arange(10), (5, 1))) and (s == 0).all()
+
+
+def _near_tied_corpus(n_groups_hit, d=256, n=64 * 400, seed=21):
+    """A corpus in which MORE 64-row groups than the selection keeps hold a row tied (to the last bit) or nearly tied with the
+    query's k-th best match: boilerplate / duplicated chunks.  One planted row per group, in `n_groups_hit` groups spread over
+    the corpus, in DEcreasing group order of quality so that 'first K groups by position' is the wrong choice."""
+    Cm = SO.unit_rows_f16(n, d, seed); Q = SO.unit_rows_f16(6, d, seed + 1)
+    rs = np.random.RandomState(seed + 2)
+    groups = rs.permutation(n // 64)[:n_groups_hit]
+    planted = []
+    for j, g in enumerate(groups):
+        row = int(g) * 64 + int(rs.randint(64))
+        v = Q[0].astype(np.float32).copy()
+        if j % 3 == 1:                                        # near tie: one coordinate moved by one fp16 ulp
+            c = int(rs.randint(d)); v[c] = np.nextafter(np.float16(v[c]), np.float16(0)).astype(np.float32)
+        elif j % 3 == 2:
+            c = int(rs.randint(d)); v[c] = np.nextafter(np.float16(v[c]), np.float16(2)).astype(np.float32)
+        Cm[row] = v.astype(np.float16)
+        planted.append(row)
+    return Cm, Q, sorted(planted)
+
+
+@pytest.mark.parametrize("k", [10, 32])
+def test_search_certificate_near_tied_groups(hip, k):
+    """>= 17 (k = 10: 12 selected; k = 32: 36 selected) groups tied or nearly tied at the top: the first selection cannot be
+    certified, the kernel must say so (flag counter) and still return exactly the oracle's rows, ties -> lower row."""
+    from arxiv_rag_amd.index import ShardIndex
+    Cm, Q, planted = _near_tied_corpus(60)
+    idx = ShardIndex(torch.from_numpy(Cm).cuda(), idx_base=1000)
+    s, i = idx.search(torch.from_numpy(Q).cuda(), k)
+    flagged, extra = idx.certificate_stats()
+    rs, ri = SO.topk_search(Cm, Q, k, idx_base=1000)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.abs(s.cpu().numpy() - rs).max() < 1e-5
+    assert set(ri[0].tolist()) <= {p + 1000 for p in planted}
+    assert flagged >= 1 and extra >= 8                                    # query 0 went through the fallback (20 exact ties alone overflow nothing less)
+    # a corpus with no such structure certifies at once
+    Cr = SO.unit_rows_f16(64 * 400, 256, 5)
+    idx2 = ShardIndex(torch.from_numpy(Cr).cuda())
+    idx2.search(torch.from_numpy(Q).cuda(), k)
+    assert idx2.certificate_stats()[0] <= 1
+
+
+def test_search_certificate_recovers_a_missed_group(hip, monkeypatch):
+    """Test hook ARX_TOPK_DEBUG_DROP=1 makes the selection forget its best group (as a rounding accident at the boundary
+    would): without the certificate the top hit would be lost; with it the answer is the oracle's.  ARX_TOPK_TAU_SCALE=1e9
+    turns the fallback into an exhaustive exact scan: same answer again."""
+    from arxiv_rag_amd.index import ShardIndex
+    Cm = SO.unit_rows_f16(30000, 384, 8); Q = SO.unit_rows_f16(40, 384, 9)
+    rs, ri = SO.topk_search(Cm, Q, 11)
+    base = ShardIndex(torch.from_numpy(Cm).cuda())
+    s0, i0 = base.search(torch.from_numpy(Q).cuda(), 10)
+    assert base.certificate_stats()[0] <= 1
+    for env in ({"ARX_TOPK_DEBUG_DROP": "1"}, {"ARX_TOPK_TAU_SCALE": "1e9"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        idx = ShardIndex(torch.from_numpy(Cm).cuda())
+        s, i = idx.search(torch.from_numpy(Q).cuda(), 10)
+        flagged, extra = idx.certificate_stats()
+        assert flagged == 40 and extra >= 40, (env, flagged, extra)
+        assert torch.equal(i, i0) and torch.equal(s, s0), env
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    i0 = i0.cpu().numpy()
+    for q in range(40):
+        if set(i0[q].tolist()) != set(ri[q, :10].tolist()):
+            assert rs[q, 9] - rs[q, 10] < 1e-6
 
 
 def test_sharded_search_equals_global(hip):
@@ -326,7 +418,7 @@ def test_collection_query_shape_and_ranking(hip, tmp_path):
         assert res["documents"][qi][0] == f"text {ri[qi][0]}" and res["metadatas"][qi][0]["paper_id"] == f"p{ri[qi][0] % 7}"
 
 
-@pytest.mark.parametrize("variant", [89, 9, 8, 13, 33, 34, 15, 1, 3, 2, 0, 4])
+@pytest.mark.parametrize("variant", [89, 9, 8, 13])
 def test_linear_layer_variants_vs_fp32(hip, variant):
     """arx_gemm_bf16 (the linear layer of the path) against an fp32 matmul on the same bf16-rounded operands:
     every main-loop schedule kept in the tree, every epilogue mode it supports, ragged M/N (masked edge tiles)."""
@@ -409,10 +501,11 @@ def test_gemm_counted_wait_schedule_race_screen(hip, variant):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("env", [{"ARX_LN_FOLD": "0"}, {"ARX_ATTN_VARIANT": "0"}, {"ARX_GEMM_VARIANT": "3"},
+@pytest.mark.parametrize("env", [{"ARX_LN_FOLD": "0"}, {"ARX_ATTN_VARIANT": "0"},
                                  {"ARX_GEMM_VARIANT": "13"}, {"ARX_GEMM_VARIANT": "8"}, {"ARX_GEMM_VARIANT": "9"}])
 def test_alternative_schedules_agree(hip, golden_dir, env, monkeypatch):
-    """The A/B schedules kept in the tree (explicit LayerNorm kernels, first attention kernel, ring GEMM) against the same
+    """The schedules shipped beside the default (explicit LayerNorm kernels, first attention kernel, 2-stage / per-tile /
+    persistent GEMM everywhere) against the same
     golden vectors as the default path, and against the default path itself."""
     from arxiv_rag_amd.encoder import HipEncoder
     g = np.load(golden_dir / "full_shapes.npz")

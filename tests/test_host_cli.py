@@ -207,6 +207,35 @@ def test_tokenizer_from_dir_vocab_txt(tmp_path):
     assert a == b
 
 
+def test_tokenizer_from_dir_tokenizer_json(tmp_path):
+    """A checkpoint directory normally carries tokenizer.json (preferred over vocab.txt): same ids as the vocab-built
+    pipeline, through both the list API and the packed (native feeder) API."""
+    cfg = C.TINY_MPNET
+    vocab = synthetic_vocab(cfg)
+    WordPieceTokenizer.from_vocab(vocab, cfg)._tok.save(str(tmp_path / "tokenizer.json"))
+    (tmp_path / "vocab.txt").write_text("not the vocabulary\n")                      # must be ignored when tokenizer.json exists
+    texts = ["alpha beta, gamma", "", "Zeta  ETA!", "x" * 150, " ".join(["ab"] * 100)]
+    a = WordPieceTokenizer.from_dir(tmp_path, cfg)
+    b = WordPieceTokenizer.from_vocab(vocab, cfg)
+    assert a.encode_batch(texts, 32) == b.encode_batch(texts, 32)
+    ia, la = a.encode_batch_packed(texts, 32)
+    assert [ia[i, :la[i]].tolist() for i in range(len(texts))] == b.encode_batch(texts, 32)
+    with pytest.raises(FileNotFoundError):
+        WordPieceTokenizer.from_dir(tmp_path / "nowhere", cfg)
+
+
+def test_loader_process_pool_equals_thread_pool(tmp_path, monkeypatch):
+    """Corpus-sized trees are parsed by a spawn-context process pool (json.load holds the GIL); the chunk list must be the
+    one the in-process path yields — sorted file order, filter applied, unreadable files skipped."""
+    make_chunk_tree(tmp_path / "in", n_files=40, chunks_per_file=3, seed=5)
+    (tmp_path / "in" / "a" / "broken.json").write_text("{not json")
+    (tmp_path / "in" / "a" / "._0704.0001.json").write_text("{}")
+    ref = GEN.load_chunks_parallel(tmp_path / "in", 0.9, 4)
+    monkeypatch.setattr(GEN, "PROCESS_POOL_MIN_FILES", 1)
+    got = GEN.load_chunks_parallel(tmp_path / "in", 0.9, 4)
+    assert got == ref and 0 < len(ref) < 120
+
+
 # ------------------------------------------------------------------ C ABI
 @pytest.mark.parametrize("preset", ["all-mpnet-base-v2", "all-MiniLM-L6-v2"])
 def test_native_wordpiece_equals_hf_pipeline_and_oracle(preset):

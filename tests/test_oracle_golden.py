@@ -76,6 +76,28 @@ def _check_full(golden_dir, key, name, rows=None):
     assert np.abs(emb - ref[rows]).max() < 5e-6
 
 
+@pytest.mark.parametrize("name,rows", [("all-MiniLM-L6-v2", None), ("all-mpnet-base-v2", [1, 6, 9, 14])])
+def test_full_shapes_adversarial_statistics(golden_dir, name, rows):
+    """The oracle on `weights.adversarial_state_dict` (wide LayerNorm affine with outlier channels, rows whose mean dwarfs their
+    spread, heavy-tailed matrices) against the transformers outputs in full_shapes_adv.npz, and the weights' digest."""
+    import hashlib
+    from arxiv_rag_amd.weights import adversarial_state_dict
+    g = np.load(golden_dir / "full_shapes_adv.npz")
+    cfg = C.PRESETS[name]
+    key = name + ":adv"
+    seed, off = g[key + ":wspec"]
+    sd = adversarial_state_dict(cfg, seed=int(seed), row_offset=float(off))
+    h = hashlib.sha256()
+    for k in sd:
+        h.update(k.encode()); h.update(np.ascontiguousarray(sd[k]).tobytes())
+    assert h.digest() == bytes(g[key + ":wdigest"])                      # the weights regenerate bit-exactly from the seed
+    ids, lens, ref = g[key + ":ids"], g[key + ":lens"], g[key + ":emb"]
+    rows = list(range(len(lens))) if rows is None else rows
+    emb = EO.encode_ragged(sd, cfg, [ids[r, :lens[r]].tolist() for r in rows], batch_size=8)
+    assert _cos(emb, ref[rows]).min() > 1 - 1e-5
+    assert np.abs(emb - ref[rows]).max() < 2e-4
+
+
 def test_relative_position_buckets(golden_dir):
     g = np.load(golden_dir / "mpnet_tables.npz")
     assert np.array_equal(EO.relative_position_bucket(g["delta"]), g["bucket_of_delta"])

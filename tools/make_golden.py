@@ -134,6 +134,35 @@ def gen_full():
     np.savez_compressed(GOLD / "full_shapes.npz", **out)
 
 
+def gen_adversarial():
+    """full_shapes_adv.npz: the full shapes again with `weights.adversarial_state_dict` (wide LayerNorm affine with outlier
+    channels, rows whose mean dwarfs their spread, heavy-tailed matrices) — the LN-fold path's worst case."""
+    from arxiv_rag_amd.weights import adversarial_state_dict
+    specs = (("all-mpnet-base-v2", [256, 200, 128, 64, 32, 16, 8, 3, 255, 129, 97, 77, 65, 33, 1, 256], 4.0),
+             ("all-MiniLM-L6-v2", [256, 200, 128, 64, 32, 16, 8, 3, 255, 129, 97, 77, 65, 33, 1, 256], 4.0),
+             ("BAAI/bge-large-en-v1.5", [256, 100, 37, 5], 4.0))
+    out = {}
+    for name, lens, off in specs:
+        cfg = C.PRESETS[name]
+        sd = adversarial_state_dict(cfg, seed=3, row_offset=off)
+        m = build_tf_model(cfg, sd)
+        lens_a = np.array(lens, np.int64)
+        ids = ragged_ids(cfg, lens_a, seed=4321)
+        h, _, emb, hs = tf_encode(m, cfg, ids, lens_a, all_hidden=True)
+        key = name.replace("/", "_") + ":adv"
+        out[key + ":emb"] = emb.astype(np.float32)
+        out[key + ":ids"] = ids
+        out[key + ":lens"] = lens_a
+        out[key + ":wspec"] = np.array([3, off], np.float64)
+        out[key + ":wdigest"] = np.frombuffer(bytes.fromhex(sd_digest(sd)), np.uint8)
+        valid = np.arange(ids.shape[1])[None] < lens_a[:, None]
+        x = hs[-1][valid]
+        print(key, emb.shape, "last hidden: mean |row mean| %.2f, mean row std %.2f, max |x| %.1f" %
+              (np.abs(x.mean(1)).mean(), x.std(1).mean(), np.abs(x).max()))
+        del m, sd
+    np.savez_compressed(GOLD / "full_shapes_adv.npz", **out)
+
+
 def gen_tables():
     from transformers.models.mpnet.modeling_mpnet import MPNetEncoder, create_position_ids_from_input_ids
     out = {}
@@ -282,4 +311,4 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "tables", "search", "harness", "semantic", "full"]
     for w in what:
         {"tiny": gen_tiny, "full": gen_full, "tables": gen_tables, "search": gen_search,
-         "harness": gen_harness, "semantic": gen_semantic}[w]()
+         "harness": gen_harness, "adversarial": gen_adversarial, "semantic": gen_semantic}[w]()
