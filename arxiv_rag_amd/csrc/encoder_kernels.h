@@ -388,6 +388,16 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     float* Bs = reinterpret_cast<float*>(smem + 2 * AttnSmem3<DH>::kv_bytes(Lk));
     const int bst = AttnSmem3<DH>::bias_stride(Lk);
 
+    // this lane's Q fragments: requested BEFORE the K/V stream so that their latency runs under it (they used to be loaded after the
+    // barrier: one more exposed memory round trip per block)
+    const int ql = lane & 31, hh = lane >> 5;
+    const int qw = q0 + wid * 32;
+    const int q = qw + ql;
+    const int qc = q < L ? q : L - 1;
+    bf16x8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (uint32_t)qc * ld + ks * 16 + hh * 8);
     {   // stage K (chunk ^ row swizzle) and V (chunk ^ 4*((row>>1)&1) for DH=64) with direct global->LDS loads: every
         // request of the block is in flight at once (one memory round trip instead of one per pass), no staging
         // registers.  This thread always owns physical chunk pc of rows r0, r0+RPI, ... (RPI % 16 == 0 keeps both
@@ -418,15 +428,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     }
     __syncthreads();
 
-    const int qw = q0 + wid * 32;
     if (qw >= L) return;
-    const int ql = lane & 31, hh = lane >> 5;
-    const int q = qw + ql;
-    const int qc = q < L ? q : L - 1;
-    bf16x8 qf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-        qf[ks] = *reinterpret_cast<const bf16x8*>(Qg + (uint32_t)qc * ld + ks * 16 + hh * 8);
     f32x16 o[DB];
 #pragma unroll
     for (int d = 0; d < DB; ++d)
@@ -554,6 +556,343 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
                 w2[1] = pack_bf16x2(o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv);
                 *reinterpret_cast<u32x2*>(orow + d * 32 + 8 * g4 + 4 * hh) = w2;
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// attention v3 ("ring"): the same arithmetic as attention_tr_kernel, bit for bit — same tiles, same MFMA order, same lazy softmax
+// reference — under a different memory schedule.  The v2 kernel stages a whole (sequence, head) before its single barrier and
+// loads Q after it: 34 % of its wave time is parked there and the matrix pipe is 28 % busy, while its HBM traffic is already
+// the algorithmic 1.0x (rocprofv3, r01).  Here a block is PERSISTENT (grid = heads x G, G = blocks per CU x CUs / heads; block
+// (g, h) walks sequences g, g + G, ... of head h) and everything it reads arrives through ONE stream of 16-KB slot-loads
+// (DH = 64; 8 KB for DH = 32) into an 8-slot LDS ring, by LDS-DMA, seven slot-loads ahead of the consumer and straight through
+// item boundaries (one 8-wave block per CU: the body needs ~170 VGPRs — at the 128 of two blocks per CU hipcc spills into the
+// tile loop, and every scratch reload is a vmcnt(0) behind the stream):
+//     item stream = [ Q part 0 (queries 0..127) , Q part 1 (if L > 128) , KV slot 0 (keys 0..63: K rows then V rows) , KV slot 1 , ... ]
+// Step j of the consumer: wait until slot-load j has landed (counted vmcnt: only the YOUNGER operations may stay in flight),
+// barrier, issue slot-load j + 7 into the slot step j - 1 just released, then either copy this wave's Q fragments to registers
+// (Q step) or run the slot's two 32-key tiles.  One barrier per step, never vmcnt(0), ~100 KB in flight per CU at any time.
+// The MPNet bias rows are staged ONCE per block (the head is fixed) around a fixed centre C0 = round32(max_len).
+// vmcnt bookkeeping is exact and wave-uniform: every slot-load is GPS global_load_lds per thread whatever the item's length
+// (rows past L re-read row L - 1); the only other vector-memory operations in the loop are the DH/8 output stores of a wave
+// that has queries in the item, written as asm so that their count is the source's (AttnStream counts both kinds).
+template <int DH> struct AttnRing {
+    static constexpr int NT = 512, NSLOT = 8, AHEAD = NSLOT - 1, SLOT_KEYS = 64;
+    static constexpr int ROWB = DH * 2;                              // bytes per K / V / Q row
+    static constexpr int SLOT_BYTES = 2 * SLOT_KEYS * ROWB;          // 64 K rows + 64 V rows, or 128 Q rows
+    static constexpr int GPS = SLOT_BYTES / (NT * 16);               // global_load_lds per thread per slot-load
+    static_assert(GPS >= 1 && GPS * NT * 16 == SLOT_BYTES, "slot must be whole passes of the block");
+    static __host__ __device__ int bias_stride(int C0) { return (2 * C0 + 8 + 52 + 63) & ~63; }
+    static __host__ __device__ int total(int C0, bool has) { return NSLOT * SLOT_BYTES + (has ? 4 * bias_stride(C0) * 4 : 0); }
+};
+
+#define ARX_VMCNT_CASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+#define ARX_VMCNT_CASE4(A, B, C_, D) ARX_VMCNT_CASE(A) ARX_VMCNT_CASE(B) ARX_VMCNT_CASE(C_) ARX_VMCNT_CASE(D)
+__device__ __forceinline__ void attn_wait_vm(int n) {      // n is wave-uniform: the younger operations that may stay in flight
+    switch (n) {
+    ARX_VMCNT_CASE4(0, 1, 2, 3) ARX_VMCNT_CASE4(4, 5, 6, 7) ARX_VMCNT_CASE4(8, 9, 10, 11) ARX_VMCNT_CASE4(12, 13, 14, 15)
+    ARX_VMCNT_CASE4(16, 17, 18, 19) ARX_VMCNT_CASE4(20, 21, 22, 23) ARX_VMCNT_CASE4(24, 25, 26, 27) ARX_VMCNT_CASE4(28, 29, 30, 31)
+    ARX_VMCNT_CASE4(32, 33, 34, 35) ARX_VMCNT_CASE4(36, 37, 38, 39) ARX_VMCNT_CASE4(40, 41, 42, 43) ARX_VMCNT_CASE(44)
+    // AHEAD - 1 = 6 younger slot-loads (12 pieces) + the stores of up to four short items that ended among them (4 x 8)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // anything larger: over-wait (safe)
+    }
+}
+#undef ARX_VMCNT_CASE4
+#undef ARX_VMCNT_CASE
+
+// The stream state of one block (every member wave-uniform: SGPRs).  Plain struct + force-inlined members: the lambda form of
+// the same code left its closures in scratch memory.
+template <int DH> struct AttnStream {
+    using R = AttnRing<DH>;
+    static constexpr int NT = R::NT, ROWB = R::ROWB, SLOT_BYTES = R::SLOT_BYTES, GPS = R::GPS, CPR = DH / 8, RPB = 256 / R::ROWB;
+    const uint16_t* qkv; const int32_t* cu; char* ring;
+    int H, h, G, n_seqs;
+    uint32_t ld;
+    int p_b, p_t0, p_L, p_step, p_nqp, p_nsteps, p_slot, c_slot;
+    // vmcnt bookkeeping without arrays: `inflight` slot-loads are outstanding (oldest = index 0); bit i of `st_bits` says that one
+    // item's output stores were issued just before slot-load i; `pend_st` counts the store operations issued since the youngest
+    // slot-load.  Operations younger than the oldest slot-load = (inflight - 1) GPS + NSTORE popcount(st_bits >> 1) + pend_st.
+    int inflight, pend_st;
+    unsigned st_bits;
+
+    __device__ __forceinline__ void p_load_item() {      // first non-empty sequence at or after p_b (stride G); p_L = 0 at the end
+        p_L = 0; p_step = 0;
+        while (p_b < n_seqs) {
+            const __attribute__((address_space(4))) int32_t* cuc = (const __attribute__((address_space(4))) int32_t*)cu;
+            const int t0 = cuc[p_b], L = cuc[p_b + 1] - t0;
+            if (L > 0) { p_t0 = t0; p_L = L; p_nqp = L > 128 ? 2 : 1; p_nsteps = p_nqp + ((L + 63) >> 6); break; }
+            p_b += G;
+        }
+    }
+    __device__ __forceinline__ void issue_next() {       // one slot-load of the producer's item into ring slot p_slot; advances the cursor
+        const uint16_t* base = qkv + (int64_t)p_t0 * ld + h * DH;
+        const bool isq = p_step < p_nqp;
+        const int r0 = isq ? 128 * p_step : 64 * (p_step - p_nqp);
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));               // opaque: the per-thread source offsets are rebuilt here (a dozen VALU ops per slot-load)
+                                                  // instead of living in a dozen VGPRs across the whole tile loop
+        char* dst = ring + p_slot * SLOT_BYTES + (__builtin_amdgcn_readfirstlane(t) & ~63) * 16;
+#pragma unroll
+        for (int it = 0; it < GPS; ++it) {
+            const int cid = it * NT + t, r128 = cid / CPR, pcn = cid % CPR;
+            int row, col0, c;
+            if (isq) { row = r0 + r128; col0 = 0; c = pcn ^ ((r128 / RPB) & (CPR - 1)); }
+            else if (r128 < 64) { row = r0 + r128; col0 = H; c = pcn ^ ((r128 / RPB) & (CPR - 1)); }
+            else { row = r0 + r128 - 64; col0 = 2 * H; c = (DH == 64) ? (pcn ^ (((r128 >> 1) & 1) << 2)) : pcn; }
+            row = row < p_L ? row : p_L - 1;      // rows past the sequence re-read its last row: finite, masked or unused
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (uint32_t)row * ld + col0 + c * 8),
+                                             (__attribute__((address_space(3))) void*)(dst + it * NT * 16), 16, 0, 0);
+        }
+        if (pend_st) st_bits |= 1u << inflight;
+        pend_st = 0;
+        ++inflight;
+        p_slot = (p_slot + 1) & (R::NSLOT - 1);
+        if (++p_step == p_nsteps) { p_b += G; p_load_item(); }
+    }
+    __device__ __forceinline__ const char* step_begin() {  // start of a consumer step: returns the slot that has just become readable
+        attn_wait_vm((inflight - 1) * GPS + (DH / 8) * __builtin_popcount(st_bits >> 1) + pend_st);   // this step's slot-load has landed (this wave's pieces) ...
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // ... and everyone's; every wave is also done with the slot of the step before
+        asm volatile("" ::: "memory");
+        st_bits >>= 1;
+        --inflight;
+        if (p_L > 0) issue_next();                // slot-load j + AHEAD -> the slot released by step j - 1
+        const char* slot = ring + c_slot * SLOT_BYTES;
+        c_slot = (c_slot + 1) & (R::NSLOT - 1);
+        return slot;
+    }
+};
+
+// one 32-key tile of the ring kernel: the tile body of attention_tr_kernel with the row sums on the 4x4x4 MFMA
+template <int DH, bool HAS_BIAS, bool MASKED, bool first>
+__device__ __forceinline__ void attn_ring_tile(const char* kbase, int k0, int v0, const bf16x8 (&qf)[DH / 16], f32x16 (&o)[DH / 32],
+                                               f32x4& lsum, float& m_run, const float* bp, int kt, int hh, int L,
+                                               float scale_log2e, float inv_scale) {
+    constexpr int KS = DH / 16, DB = DH / 32, ROWB = DH * 2;
+    constexpr float THR = 8.0f;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    f32x16 s;
+    const float s0 = first ? 0.f : -m_run * inv_scale;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = s0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase + (k0 ^ (ks << 5)));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (HAS_BIAS) bv = *reinterpret_cast<const f32x4*>(bp + 8 * g4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = fmaf(s[g4 * 4 + e], scale_log2e, bv[e]);
+            if (MASKED) v = (kt * 32 + 8 * g4 + 4 * hh + e < L) ? v : -INFINITY;
+            s[g4 * 4 + e] = v;
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));           // tile maximum relative to the reference (first tile: absolute, finite: key 0 is valid)
+    if (first) {                                  // no reference yet: take the exact maximum (O and the row sums are still zero)
+        m_run = mx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] -= mx;
+    } else if (__any(mx > THR)) {                 // move the reference: lanes whose maximum did not grow keep theirs (d = 0)
+        const float d = fmaxf(mx, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        m_run += d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] -= d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lsum[r] *= alpha;
+#pragma unroll
+        for (int dd = 0; dd < DB; ++dd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+    bf16x8 pf[2];
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[ss][e] = (bf16_t)s[8 * ss + e];
+    // row sums on the matrix pipe: the 4x4x4 MFMA with A = ones adds each lane's own four B values into its accumulator
+    const s16x4 one4 = s16x4{0x3f80, 0x3f80, 0x3f80, 0x3f80};
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+        const s16x8 p8 = __builtin_bit_cast(s16x8, pf[ss]);
+        lsum = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, s16x4{p8[0], p8[1], p8[2], p8[3]}, lsum, 0, 0, 0);
+        lsum = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, s16x4{p8[4], p8[5], p8[6], p8[7]}, lsum, 0, 0, 0);
+    }
+    // V^T operands by the transposing LDS read, written as asm: behind the BUILTIN hipcc puts s_waitcnt vmcnt(0) (it cannot tell
+    // the read from the ring's in-flight LDS-DMA writes), which would drain the stream twice per tile.  LDS operations return in
+    // order, so the compiler's own counted lgkmcnt waits stay valid beside these; ours is lgkmcnt(0) and names every destination.
+    s16x4 vt[DB][2][2];
+    const uint32_t vaddr = (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)kbase + (uint32_t)v0;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+        const uint32_t va = vaddr ^ (uint32_t)(d << 6);       // kbase is 64-B aligned and v0 < 2^16: the xor acts on v0's bit 6 only
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[d][ss][0]) : "v"(va), "n"((16 * ss) * ROWB));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[d][ss][1]) : "v"(va), "n"((16 * ss + 8) * ROWB));
+        }
+    }
+    if constexpr (DB == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
+                                              "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]) :: "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]) :: "memory");
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            s16x8 v8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v8[e] = vt[d][ss][0][e]; v8[4 + e] = vt[d][ss][1][e]; }
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf[ss], o[d], 0, 0, 0);
+        }
+    }
+}
+
+template <int DH, bool HAS_BIAS>
+__global__ __launch_bounds__(512, 2) void attention_ring_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
+                                                                 const int32_t* __restrict__ cu,
+                                                                 const float* __restrict__ bias_tbl, int H, int n_seqs,
+                                                                 int C0, float scale_log2e) {
+    using R = AttnRing<DH>;
+    constexpr int NT = R::NT, ROWB = R::ROWB, SLOT_BYTES = R::SLOT_BYTES, GPS = R::GPS;
+    constexpr int CPR = DH / 8;                   // 16-B chunks per row
+    constexpr int RPB = 256 / ROWB;               // rows per 256-B bank row
+    constexpr int KS = DH / 16;
+    constexpr int DB = DH / 32;
+    constexpr int NSTORE = DB * 4;                // output stores per lane per item
+    static_assert((R::AHEAD - 1) * GPS + 4 * NSTORE <= 44, "attn_wait_vm covers AHEAD - 1 younger slot-loads plus four items' stores");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int heads = H / DH;
+    const int h = blockIdx.x % heads, g = blockIdx.x / heads, G = gridDim.x / heads;
+    float* const Bs = reinterpret_cast<float*>(smem + R::NSLOT * SLOT_BYTES);
+    const int bst = R::bias_stride(C0);
+
+    if (HAS_BIAS) {      // four shifted copies of this head's Toeplitz row around the fixed centre C0: once per block
+        const float* bt = bias_tbl + (int64_t)h * ARX_BIAS_ROW + ARX_BIAS_CENTER;
+        const int span = 2 * C0 + 8;
+        for (int i = tid; i < 4 * span; i += NT) {
+            const int c = i / span, j = i - c * span;
+            int d = j + c - C0;
+            d = d < -ARX_BIAS_CENTER ? -ARX_BIAS_CENTER : (d > ARX_BIAS_CENTER ? ARX_BIAS_CENTER : d);
+            Bs[c * bst + attn_bias_off(c) + j] = bt[d];
+        }
+    }
+    __syncthreads();                              // (also drains the bias loads: nothing is in flight when the stream starts)
+
+    AttnStream<DH> st;
+    st.qkv = qkv; st.cu = cu; st.ring = smem; st.H = H; st.h = h; st.G = G; st.n_seqs = n_seqs; st.ld = 3u * (uint32_t)H;
+    st.p_b = g; st.p_t0 = 0; st.p_L = 0; st.p_step = 0; st.p_nqp = 0; st.p_nsteps = 0; st.p_slot = 0; st.c_slot = 0;
+    st.inflight = 0; st.pend_st = 0; st.st_bits = 0u;
+    st.p_load_item();
+    if (st.p_L == 0) return;                      // block-uniform: no work for this block
+#pragma unroll 1
+    for (int i = 0; i < R::AHEAD && st.p_L > 0; ++i) st.issue_next();
+
+    // ---- per-lane constants of the tile body (byte offsets inside a slot)
+    const int ql = lane & 31, hh = lane >> 5;
+    // fragment ks of this lane's K row sits at k0 ^ (ks << 5): 2 ks + hh and the row swizzle occupy disjoint bits of the chunk index
+    const int k0 = ql * ROWB + ((hh ^ ((ql / RPB) & (CPR - 1))) << 4);
+    const int q_ = (lane & 15) >> 2, p_ = lane & 3;
+    const int vsw = (DH == 64) ? (((q_ >> 1) & 1) << 2) : 0;
+    // V fragment offsets: block d of the head dimension sits at v0 ^ (d << 6) (d selects bit 2 of the chunk index)
+    const int v0 = 64 * ROWB + (4 * hh + q_) * ROWB + ((((16 * ((lane >> 4) & 1) + 4 * p_) >> 3) ^ vsw) << 4) + ((p_ & 1) << 3);
+    const float inv_scale = 1.0f / scale_log2e;
+
+    int b = g;
+#pragma unroll 1
+    for (;;) {
+        // ---- next item of the consumer (same walk as the producer's)
+        int t0 = 0, L = 0;
+        while (b < n_seqs) {                      // scalar loads (constant address space): a vector load here would be a vmcnt(0) per item
+            const __attribute__((address_space(4))) int32_t* cuc = (const __attribute__((address_space(4))) int32_t*)cu;
+            t0 = cuc[b]; L = cuc[b + 1] - t0;
+            if (L > 0) break;
+            b += G;
+        }
+        if (b >= n_seqs) break;
+        const int nqp = L > 128 ? 2 : 1, nkv = (L + 63) >> 6, nkt = (L + 31) >> 5;
+        const bool wave_on = wid * 32 < L;        // wave-uniform (wid is an SGPR)
+        bf16x8 qf[KS];
+        f32x16 o[DB];
+        f32x4 lsum = f32x4{0.f, 0.f, 0.f, 0.f};   // per-lane sum of its bf16-rounded probabilities (all four entries equal)
+        float m_run = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16_t)0.f;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+        const int q = wid * 32 + ql, qc = q < L ? q : L - 1;
+        const int bc = (4 - (qc & 3)) & 3;
+        const float* bptr = Bs + bc * bst + attn_bias_off(bc) + (C0 - qc - bc) + 4 * hh;
+
+        // ---- Q steps: the waves of each 128-query part copy their fragments to registers
+#pragma unroll 1
+        for (int p = 0; p < nqp; ++p) {
+            const char* slot = st.step_begin();
+            if (wave_on && (wid >> 2) == p) {
+                const int r = (wid & 3) * 32 + ql;
+                const char* qrow = slot + r * ROWB;
+                const int sw = (r / RPB) & (CPR - 1);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + (((2 * ks + hh) ^ sw) << 4));
+            }
+        }
+        // ---- KV steps: two 32-key tiles each
+        const bool ragged = (L & 31) != 0;
+#pragma unroll 1
+        for (int sidx = 0; sidx < nkv; ++sidx) {
+            const char* slot = st.step_begin();
+            if (wave_on) {
+#pragma unroll 1
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int kt = 2 * sidx + t2;
+                    if (kt >= nkt) break;
+                    const char* kbase = slot + t2 * 32 * ROWB;
+                    const bool msk = ragged && kt == nkt - 1;
+                    if (kt == 0) {
+                        if (msk) attn_ring_tile<DH, HAS_BIAS, true, true>(kbase, k0, v0, qf, o, lsum, m_run, bptr, kt, hh, L, scale_log2e, inv_scale);
+                        else attn_ring_tile<DH, HAS_BIAS, false, true>(kbase, k0, v0, qf, o, lsum, m_run, bptr, kt, hh, L, scale_log2e, inv_scale);
+                    } else {
+                        if (msk) attn_ring_tile<DH, HAS_BIAS, true, false>(kbase, k0, v0, qf, o, lsum, m_run, bptr + 32 * kt, kt, hh, L, scale_log2e, inv_scale);
+                        else attn_ring_tile<DH, HAS_BIAS, false, false>(kbase, k0, v0, qf, o, lsum, m_run, bptr + 32 * kt, kt, hh, L, scale_log2e, inv_scale);
+                    }
+                }
+            }
+        }
+        // ---- item done: normalise and store this wave's rows
+        if (wave_on) {
+            const float l_tot = lsum[0] + __shfl_xor(lsum[0], 32);      // the two lane halves hold disjoint keys of the same query
+            const float inv = 1.0f / l_tot;
+            uint16_t* orow = ctx + (int64_t)(t0 + qc) * H + h * DH + 4 * hh;
+            if (q < L) {
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        u32x2 w2;
+                        w2[0] = pack_bf16x2(o[d][g4 * 4 + 0] * inv, o[d][g4 * 4 + 1] * inv);
+                        w2[1] = pack_bf16x2(o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv);
+                        asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" :: "v"(orow + d * 32 + 8 * g4), "v"(w2) : "memory");
+                    }
+            }
+            st.pend_st += NSTORE;                 // lane 0 of an active wave always has q < L: the stores were issued
+        }
+        b += G;
     }
 }
 
