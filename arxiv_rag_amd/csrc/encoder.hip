@@ -413,11 +413,11 @@ static int launch_attn_tr_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream
     return ARX_OK;
 }
 
-template <int DH, bool HB>
+template <int DH, bool HB, int NSLOT>
 static int launch_attn_ring_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
-    auto kern = attention_ring_kernel<DH, HB>;
+    auto kern = attention_ring_kernel<DH, HB, NSLOT>;
     const int C0 = (max_len + 31) & ~31;
-    const int smem = AttnRing<DH>::total(C0, HB);
+    const int smem = AttnRing<DH, NSLOT>::total(C0, HB);
     ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem));
     int G = arx_device_cus() / h->cfg.heads;                      // one persistent 8-wave block per CU (the ring takes most of its LDS)
     G = G < 1 ? 1 : (G > n_seqs ? n_seqs : G);
@@ -431,9 +431,9 @@ static int launch_attn_ring_cfg(arx_encoder* h, int n_seqs, int max_len, hipStre
 static int launch_attn(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
     const int dh = h->cfg.hidden / h->cfg.heads;
     const bool hb = h->cfg.arch == ARX_ARCH_MPNET;
-    if (h->attn_variant == 2 && max_len > 128 && max_len <= 256) {      // streaming ring kernel (encoder_kernels.h "attention v3")
-        if (dh == 64) return hb ? launch_attn_ring_cfg<64, true>(h, n_seqs, max_len, st) : launch_attn_ring_cfg<64, false>(h, n_seqs, max_len, st);
-        return hb ? launch_attn_ring_cfg<32, true>(h, n_seqs, max_len, st) : launch_attn_ring_cfg<32, false>(h, n_seqs, max_len, st);
+    if (h->attn_variant == 2 && max_len > 128 && max_len <= 256) {      // streaming ring kernel (encoder_kernels.h "attention v3"), one block per CU
+        if (dh == 64) return hb ? launch_attn_ring_cfg<64, true, 8>(h, n_seqs, max_len, st) : launch_attn_ring_cfg<64, false, 8>(h, n_seqs, max_len, st);
+        return hb ? launch_attn_ring_cfg<32, true, 8>(h, n_seqs, max_len, st) : launch_attn_ring_cfg<32, false, 8>(h, n_seqs, max_len, st);
     }
     if (h->attn_variant >= 1) {      // transposing-read kernel; 8 waves cover 256 queries, 4 waves for short batches
         const bool w8 = max_len > 128;

@@ -576,8 +576,8 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
 // vmcnt bookkeeping is exact and wave-uniform: every slot-load is GPS global_load_lds per thread whatever the item's length
 // (rows past L re-read row L - 1); the only other vector-memory operations in the loop are the DH/8 output stores of a wave
 // that has queries in the item, written as asm so that their count is the source's (AttnStream counts both kinds).
-template <int DH> struct AttnRing {
-    static constexpr int NT = 512, NSLOT = 8, AHEAD = NSLOT - 1, SLOT_KEYS = 64;
+template <int DH, int NSLOT_ = 8> struct AttnRing {
+    static constexpr int NT = 512, NSLOT = NSLOT_, AHEAD = NSLOT - 1, SLOT_KEYS = 64;
     static constexpr int ROWB = DH * 2;                              // bytes per K / V / Q row
     static constexpr int SLOT_BYTES = 2 * SLOT_KEYS * ROWB;          // 64 K rows + 64 V rows, or 128 Q rows
     static constexpr int GPS = SLOT_BYTES / (NT * 16);               // global_load_lds per thread per slot-load
@@ -602,8 +602,8 @@ __device__ __forceinline__ void attn_wait_vm(int n) {      // n is wave-uniform:
 
 // The stream state of one block (every member wave-uniform: SGPRs).  Plain struct + force-inlined members: the lambda form of
 // the same code left its closures in scratch memory.
-template <int DH> struct AttnStream {
-    using R = AttnRing<DH>;
+template <int DH, int NSLOT> struct AttnStream {
+    using R = AttnRing<DH, NSLOT>;
     static constexpr int NT = R::NT, ROWB = R::ROWB, SLOT_BYTES = R::SLOT_BYTES, GPS = R::GPS, CPR = DH / 8, RPB = 256 / R::ROWB;
     const uint16_t* qkv; const int32_t* cu; char* ring;
     int H, h, G, n_seqs;
@@ -715,56 +715,48 @@ __device__ __forceinline__ void attn_ring_tile(const char* kbase, int k0, int v0
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+    // P as bf16: one v_cvt_pk_bf16_f32 per pair; pw[4 ss + j] holds elements 2j, 2j + 1 of k-step ss
+    uint32_t pw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pw[j] = pack_bf16x2(s[2 * j], s[2 * j + 1]);
     bf16x8 pf[2];
 #pragma unroll
-    for (int ss = 0; ss < 2; ++ss)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pf[ss][e] = (bf16_t)s[8 * ss + e];
+    for (int ss = 0; ss < 2; ++ss) pf[ss] = __builtin_bit_cast(bf16x8, u32x4{pw[4 * ss], pw[4 * ss + 1], pw[4 * ss + 2], pw[4 * ss + 3]});
     // row sums on the matrix pipe: the 4x4x4 MFMA with A = ones adds each lane's own four B values into its accumulator
     const s16x4 one4 = s16x4{0x3f80, 0x3f80, 0x3f80, 0x3f80};
 #pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-        const s16x8 p8 = __builtin_bit_cast(s16x8, pf[ss]);
-        lsum = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, s16x4{p8[0], p8[1], p8[2], p8[3]}, lsum, 0, 0, 0);
-        lsum = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, s16x4{p8[4], p8[5], p8[6], p8[7]}, lsum, 0, 0, 0);
-    }
+    for (int j = 0; j < 4; ++j)
+        lsum = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, __builtin_bit_cast(s16x4, u32x2{pw[2 * j], pw[2 * j + 1]}), lsum, 0, 0, 0);
     // V^T operands by the transposing LDS read, written as asm: behind the BUILTIN hipcc puts s_waitcnt vmcnt(0) (it cannot tell
     // the read from the ring's in-flight LDS-DMA writes), which would drain the stream twice per tile.  LDS operations return in
     // order, so the compiler's own counted lgkmcnt waits stay valid beside these; ours is lgkmcnt(0) and names every destination.
-    s16x4 vt[DB][2][2];
     const uint32_t vaddr = (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)kbase + (uint32_t)v0;
 #pragma unroll
     for (int d = 0; d < DB; ++d) {
         const uint32_t va = vaddr ^ (uint32_t)(d << 6);       // kbase is 64-B aligned and v0 < 2^16: the xor acts on v0's bit 6 only
+        s16x4 vt[2][2];
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[d][ss][0]) : "v"(va), "n"((16 * ss) * ROWB));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[d][ss][1]) : "v"(va), "n"((16 * ss + 8) * ROWB));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[ss][0]) : "v"(va), "n"((16 * ss) * ROWB));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[ss][1]) : "v"(va), "n"((16 * ss + 8) * ROWB));
         }
-    }
-    if constexpr (DB == 2)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]),
-                                              "+v"(vt[1][0][0]), "+v"(vt[1][0][1]), "+v"(vt[1][1][0]), "+v"(vt[1][1][1]) :: "memory");
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[0][0][0]), "+v"(vt[0][0][1]), "+v"(vt[0][1][0]), "+v"(vt[0][1][1]) :: "memory");
-#pragma unroll
-    for (int d = 0; d < DB; ++d) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[0][0]), "+v"(vt[0][1]), "+v"(vt[1][0]), "+v"(vt[1][1]) :: "memory");
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
             s16x8 v8;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v8[e] = vt[d][ss][0][e]; v8[4 + e] = vt[d][ss][1][e]; }
+            for (int e = 0; e < 4; ++e) { v8[e] = vt[ss][0][e]; v8[4 + e] = vt[ss][1][e]; }
             o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf[ss], o[d], 0, 0, 0);
         }
     }
 }
 
-template <int DH, bool HAS_BIAS>
+template <int DH, bool HAS_BIAS, int NSLOT>
 __global__ __launch_bounds__(512, 2) void attention_ring_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
                                                                  const int32_t* __restrict__ cu,
                                                                  const float* __restrict__ bias_tbl, int H, int n_seqs,
                                                                  int C0, float scale_log2e) {
-    using R = AttnRing<DH>;
+    using R = AttnRing<DH, NSLOT>;
     constexpr int NT = R::NT, ROWB = R::ROWB, SLOT_BYTES = R::SLOT_BYTES, GPS = R::GPS;
     constexpr int CPR = DH / 8;                   // 16-B chunks per row
     constexpr int RPB = 256 / ROWB;               // rows per 256-B bank row
@@ -791,7 +783,7 @@ __global__ __launch_bounds__(512, 2) void attention_ring_kernel(const uint16_t* 
     }
     __syncthreads();                              // (also drains the bias loads: nothing is in flight when the stream starts)
 
-    AttnStream<DH> st;
+    AttnStream<DH, NSLOT> st;
     st.qkv = qkv; st.cu = cu; st.ring = smem; st.H = H; st.h = h; st.G = G; st.n_seqs = n_seqs; st.ld = 3u * (uint32_t)H;
     st.p_b = g; st.p_t0 = 0; st.p_L = 0; st.p_step = 0; st.p_nqp = 0; st.p_nsteps = 0; st.p_slot = 0; st.c_slot = 0;
     st.inflight = 0; st.pend_st = 0; st.st_bits = 0u;
