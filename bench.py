@@ -89,6 +89,9 @@ def _cpu_fanout(model_name, cfg, sd, S, workers, budget_s, B=4, timeout_s=240.0)
     try:
         np.savez(wpath, **sd)
         env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        shim = ROOT / "oracle" / "_build" / "libnogpu.so"       # CPU workers must not hold the GPU device node (oracle/nogpu_shim.c)
+        if shim.exists():
+            env["LD_PRELOAD"] = (str(shim) + " " + env.get("LD_PRELOAD", "")).strip()
         cmd = [sys.executable, str(ROOT / "oracle" / "cpu_fanout_worker.py"), str(ROOT), model_name, wpath, str(S), str(B), str(budget_s)]
         def spawn():
             procs.append(subprocess.Popen(cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env))
