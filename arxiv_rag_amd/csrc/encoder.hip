@@ -428,9 +428,26 @@ static int launch_attn_ring_cfg(arx_encoder* h, int n_seqs, int max_len, hipStre
     return ARX_OK;
 }
 
+template <bool HB>
+static int launch_attn_ring16_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
+    auto kern = attention_ring16_kernel<HB>;
+    const int C0 = (max_len + 31) & ~31;
+    const int smem = AttnRing16<8>::total(C0, HB);
+    ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem));
+    int G = arx_device_cus() / h->cfg.heads;                      // one persistent 16-wave block per CU
+    G = G < 1 ? 1 : (G > n_seqs ? n_seqs : G);
+    const float scale_log2e = 1.4426950408889634f / sqrtf(64.0f);
+    ProfScope ps(ARX_K_ATTENTION, st);
+    kern<<<G * h->cfg.heads, 1024, smem, st>>>(h->qkv, h->ctx, h->cu, h->bias_tbl, h->cfg.hidden, n_seqs, C0, scale_log2e);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
 static int launch_attn(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
     const int dh = h->cfg.hidden / h->cfg.heads;
     const bool hb = h->cfg.arch == ARX_ARCH_MPNET;
+    if (h->attn_variant == 4 && dh == 64 && max_len > 128 && max_len <= 256)      // 16-wave ring kernel (encoder_kernels.h "attention v4")
+        return hb ? launch_attn_ring16_cfg<true>(h, n_seqs, max_len, st) : launch_attn_ring16_cfg<false>(h, n_seqs, max_len, st);
     if (h->attn_variant == 2 && max_len > 128 && max_len <= 256) {      // streaming ring kernel (encoder_kernels.h "attention v3"), one block per CU
         if (dh == 64) return hb ? launch_attn_ring_cfg<64, true, 8>(h, n_seqs, max_len, st) : launch_attn_ring_cfg<64, false, 8>(h, n_seqs, max_len, st);
         return hb ? launch_attn_ring_cfg<32, true, 8>(h, n_seqs, max_len, st) : launch_attn_ring_cfg<32, false, 8>(h, n_seqs, max_len, st);
@@ -467,6 +484,17 @@ extern "C" int32_t arx_encoder_attention(arx_encoder* h, const void* qkv, const 
     const int rc = launch_attn(h, n_seqs, max_len, st);
     h->qkv = q0; h->ctx = c0;
     return rc;
+}
+
+static void launch_ln_finalize(int T, int nparts, const float* ps, const float* pq, int64_t ld, const int32_t* n_rows, float inv_h,
+                               float eps, float* mean, float* rstd, hipStream_t st) {
+    const int grid = cdiv(T, 256);
+    switch (nparts) {      // same order of additions whatever the instantiation
+    case 6: ln_finalize_kernel<6><<<grid, 256, 0, st>>>(ps, pq, ld, nparts, n_rows, inv_h, eps, mean, rstd); break;
+    case 12: ln_finalize_kernel<12><<<grid, 256, 0, st>>>(ps, pq, ld, nparts, n_rows, inv_h, eps, mean, rstd); break;
+    case 16: ln_finalize_kernel<16><<<grid, 256, 0, st>>>(ps, pq, ld, nparts, n_rows, inv_h, eps, mean, rstd); break;
+    default: ln_finalize_kernel<0><<<grid, 256, 0, st>>>(ps, pq, ld, nparts, n_rows, inv_h, eps, mean, rstd); break;
+    }
 }
 
 // ---- forward ------------------------------------------------------------------------------------
@@ -567,7 +595,7 @@ extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32
             if ((rc = launch_gemm<EPI_LNRESID_STATS>(ARX_K_GEMM_OPROJ, h->variant, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st)) != ARX_OK) return rc;
         }
         { ProfScope ps(ARX_K_LAYERNORM, st);
-          ln_finalize_kernel<<<cdiv(T, 256), 256, 0, st>>>(h->part_s, h->part_q, tp, H / 64, h->cu + n_seqs, inv_h, c.ln_eps, h->st1_sum, h->st1_sq); }
+          launch_ln_finalize(T, H / 64, h->part_s, h->part_q, tp, h->cu + n_seqs, inv_h, c.ln_eps, h->st1_sum, h->st1_sq, st); }
         ARX_HIP_CHECK(hipGetLastError());
         // hbuf = gelu(LN1(y1) W1^T + b1)   (gamma1 folded into W1')
         ep = EpiParams{h->hbuf, F, h->c_fc1[li], nullptr, 0};
@@ -579,7 +607,7 @@ extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32
         ep.o_sum = h->part_s; ep.o_sq = h->part_q; ep.o_ld = tp; ep.inv_h = inv_h; ep.eps = c.ln_eps;
         if ((rc = launch_gemm<EPI_LNRESID_STATS>(ARX_K_GEMM_FC2, h->variant, h->hbuf, F, (const uint16_t*)L.w_fc2, F, T, H, F, ep, st)) != ARX_OK) return rc;
         { ProfScope ps(ARX_K_LAYERNORM, st);
-          ln_finalize_kernel<<<cdiv(T, 256), 256, 0, st>>>(h->part_s, h->part_q, tp, H / 64, h->cu + n_seqs, inv_h, c.ln_eps, h->st2_sum, h->st2_sq); }
+          launch_ln_finalize(T, H / 64, h->part_s, h->part_q, tp, h->cu + n_seqs, inv_h, c.ln_eps, h->st2_sum, h->st2_sq, st); }
         ARX_HIP_CHECK(hipGetLastError());
         if (h->tap_layer == li + 1 && h->tap) {       // parity tap: materialise LN2(y2) with the stand-alone kernel
             layernorm_kernel<<<ln_grid, 256, 0, st>>>(h->x, h->tap, L.ln2_g, L.ln2_b, h->cu + n_seqs, H, c.ln_eps);

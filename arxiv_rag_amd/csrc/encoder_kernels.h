@@ -889,6 +889,305 @@ __global__ __launch_bounds__(512, 2) void attention_ring_kernel(const uint16_t* 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// attention v4 ("ring16"): the v3 stream (persistent block per CU, 8-slot LDS ring, LDS-DMA seven slot-loads ahead, counted
+// vmcnt) under SIXTEEN waves of 16 queries on mfma_f32_16x16x32_bf16.  v3 showed where the time goes once staging no longer
+// stalls: a 32-query wave's tile is a ~2 k-cycle dependency chain (LDS reads -> 4 chained MFMAs -> max / exchange / exp / convert
+// -> transposing reads -> PV), its state needs ~165 VGPRs, so one 8-wave block per CU leaves two waves per SIMD and nothing to
+// cover that chain with (0.71 ms against v2's 0.42 ms, same box).  A 16-query wave halves every per-wave array (O^T 16 regs,
+// S^T 8, Q 8), fits 128 VGPRs, and a 16-wave block puts FOUR waves on each SIMD with the whole LDS still free for the ring.
+//   S^T block [16 keys x 16 queries] = K rows . Q^T: lane l holds query l & 15 and keys 4 (l >> 4) + r of the block in its 4
+//   accumulator registers; two blocks (keys 0-15, 16-31 of the tile) give the lane 8 probabilities which ARE its B fragment of
+//   O^T[16 dh x 16 q] += V^T[16 dh x 32 k] . P^T[32 k x 16 q] under the k <-> key map  k = 8 g + j  ->  key 16 (j >> 2) + 4 g + (j & 3):
+//   no lane movement; the V^T operand under the same map is two ds_read_b64_tr_b16 (rows 4 g .. 4 g + 3 and 16 + 4 g ..).
+//   Row maxima cross the four lane groups by v_permlane16/32 swaps; row sums stay per lane until the item ends.
+// LDS images: K and Q rows as in v2/v3 (16-B chunk ^ ((row >> 1) & 7): the 16-row x 4-chunk fragment read is conflict-free);
+// V rows with chunk ^ (((row >> 1) & 3) << 1), which spreads the transposing read's rows 4 g + q over the four 32-B column
+// windows of a bank half.
+template <int NSLOT_ = 8> struct AttnRing16 {
+    static constexpr int DH = 64, NT = 1024, NSLOT = NSLOT_, AHEAD = NSLOT - 1;
+    static constexpr int ROWB = DH * 2, SLOT_BYTES = 128 * ROWB;     // 64 K rows + 64 V rows, or 128 Q rows: one 16-B piece per thread
+    static __host__ __device__ int bias_stride(int C0) { return (2 * C0 + 8 + 52 + 63) & ~63; }
+    static __host__ __device__ int total(int C0, bool has) { return NSLOT * SLOT_BYTES + (has ? 4 * bias_stride(C0) * 4 : 0); }
+};
+
+struct AttnStream16 {
+    using R = AttnRing16<8>;
+    const uint16_t* qkv; const int32_t* cu; char* ring;
+    int H, h, G, n_seqs;
+    uint32_t ld;
+    int p_b, p_t0, p_L, p_step, p_nqp, p_nsteps, p_slot, c_slot;
+    int inflight, pend_st;                        // bookkeeping as in AttnStream (one piece per slot-load, 4 stores per item and lane)
+    unsigned st_bits;
+
+    __device__ __forceinline__ void p_load_item() {
+        p_L = 0; p_step = 0;
+        while (p_b < n_seqs) {
+            const __attribute__((address_space(4))) int32_t* cuc = (const __attribute__((address_space(4))) int32_t*)cu;
+            const int t0 = cuc[p_b], L = cuc[p_b + 1] - t0;
+            if (L > 0) { p_t0 = t0; p_L = L; p_nqp = L > 128 ? 2 : 1; p_nsteps = p_nqp + ((L + 63) >> 6); break; }
+            p_b += G;
+        }
+    }
+    __device__ __forceinline__ void issue_next() {
+        const uint16_t* base = qkv + (int64_t)p_t0 * ld + h * 64;
+        const bool isq = p_step < p_nqp;
+        const int r0 = isq ? 128 * p_step : 64 * (p_step - p_nqp);
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));               // opaque: source offsets rebuilt per slot-load, not kept in VGPRs across the tile loop
+        char* dst = ring + p_slot * R::SLOT_BYTES + (__builtin_amdgcn_readfirstlane(t) & ~63) * 16;
+        const int r128 = t >> 3, pcn = t & 7;
+        int row, col0, c;
+        if (isq) { row = r0 + r128; col0 = 0; c = pcn ^ ((r128 >> 1) & 7); }
+        else if (r128 < 64) { row = r0 + r128; col0 = H; c = pcn ^ ((r128 >> 1) & 7); }
+        else { row = r0 + r128 - 64; col0 = 2 * H; c = pcn ^ (((r128 >> 1) & 3) << 1); }
+        row = row < p_L ? row : p_L - 1;          // rows past the sequence re-read its last row: finite, masked or unused
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (uint32_t)row * ld + col0 + c * 8),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        if (pend_st) st_bits |= 1u << inflight;
+        pend_st = 0;
+        ++inflight;
+        p_slot = (p_slot + 1) & (R::NSLOT - 1);
+        if (++p_step == p_nsteps) { p_b += G; p_load_item(); }
+    }
+    __device__ __forceinline__ const char* step_begin() {
+        attn_wait_vm((inflight - 1) + 4 * __builtin_popcount(st_bits >> 1) + pend_st);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        st_bits >>= 1;
+        --inflight;
+        if (p_L > 0) issue_next();
+        const char* slot = ring + c_slot * R::SLOT_BYTES;
+        c_slot = (c_slot + 1) & (R::NSLOT - 1);
+        return slot;
+    }
+};
+
+template <bool HAS_BIAS, bool MASKED, bool FIRST>
+__device__ __forceinline__ void attn_ring16_tile(const char* kbase, int k0, uint32_t v0, const bf16x8 (&qf)[2], f32x4 (&o)[4], f32x4& lsum,
+                                                 float& m_run, const float* bp, int kt, int g, int L, float scale_log2e, float inv_scale) {
+    constexpr int ROWB = 128;
+    constexpr float THR = 8.0f;
+    // ---- S^T for the tile's two 16-key blocks: 2 x 2 MFMAs, two independent accumulators
+    f32x4 s[2];
+    const float s0 = FIRST ? 0.f : -m_run * inv_scale;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        s[kb] = f32x4{s0, s0, s0, s0};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kbase + kb * 16 * ROWB + (k0 ^ (ks << 6)));
+            s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (HAS_BIAS) bv = *reinterpret_cast<const f32x4*>(bp + 16 * kb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = fmaf(s[kb][e], scale_log2e, bv[e]);
+            if (MASKED) v = (kt * 32 + 16 * kb + 4 * g + e < L) ? v : -INFINITY;
+            s[kb][e] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    // maximum over the four lane groups that share this query (lanes l, l ^ 16, l ^ 32, l ^ 48)
+    {
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    }
+    if (FIRST) {
+        m_run = mx;                               // finite: key 0 is valid
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[kb][e] -= mx;
+    } else if (__any(mx > THR)) {
+        const float d = fmaxf(mx, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        m_run += d;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[kb][e] -= d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lsum[r] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[db][r] *= alpha;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[kb][e] = __builtin_amdgcn_exp2f(s[kb][e]);
+    // P^T fragment: element j = 4 kb + e  <->  key 16 kb + 4 g + e  (the k <-> key map of the header)
+    uint32_t pw[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        pw[2 * kb] = pack_bf16x2(s[kb][0], s[kb][1]);
+        pw[2 * kb + 1] = pack_bf16x2(s[kb][2], s[kb][3]);
+    }
+    const bf16x8 pf = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+    typedef short s16x4_ __attribute__((ext_vector_type(4)));
+    typedef short s16x8_ __attribute__((ext_vector_type(8)));
+    const s16x4_ one4 = s16x4_{0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    lsum = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, __builtin_bit_cast(s16x4_, u32x2{pw[0], pw[1]}), lsum, 0, 0, 0);
+    lsum = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, __builtin_bit_cast(s16x4_, u32x2{pw[2], pw[3]}), lsum, 0, 0, 0);
+    // ---- O^T += V^T . P^T: per 16-row block of the head dimension two transposing reads (keys 4 g + q, 16 + 4 g + q) and one MFMA
+    const uint32_t kb_lds = (uint32_t)(size_t)(const __attribute__((address_space(3))) char*)kbase;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        s16x4_ vt[2][2];
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2) {
+            const uint32_t va = kb_lds + (v0 ^ (uint32_t)((2 * half + d2) << 5));   // block db moves the 32-B column window: bits 5, 6 of the row offset
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vt[d2][0]) : "v"(va));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vt[d2][1]) : "v"(va), "n"(16 * ROWB));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vt[0][0]), "+v"(vt[0][1]), "+v"(vt[1][0]), "+v"(vt[1][1]) :: "memory");
+#pragma unroll
+        for (int d2 = 0; d2 < 2; ++d2) {
+            s16x8_ v8;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v8[e] = vt[d2][0][e]; v8[4 + e] = vt[d2][1][e]; }
+            o[2 * half + d2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v8), pf, o[2 * half + d2], 0, 0, 0);
+        }
+    }
+}
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(1024, 4) void attention_ring16_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
+                                                                    const int32_t* __restrict__ cu,
+                                                                    const float* __restrict__ bias_tbl, int H, int n_seqs,
+                                                                    int C0, float scale_log2e) {
+    using R = AttnRing16<8>;
+    constexpr int NT = R::NT, ROWB = R::ROWB, SLOT_BYTES = R::SLOT_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int heads = H / 64;
+    const int h = blockIdx.x % heads, g_blk = blockIdx.x / heads, G = gridDim.x / heads;
+    float* const Bs = reinterpret_cast<float*>(smem + R::NSLOT * SLOT_BYTES);
+    const int bst = R::bias_stride(C0);
+    if (HAS_BIAS) {
+        const float* bt = bias_tbl + (int64_t)h * ARX_BIAS_ROW + ARX_BIAS_CENTER;
+        const int span = 2 * C0 + 8;
+        for (int i = tid; i < 4 * span; i += NT) {
+            const int c = i / span, j = i - c * span;
+            int d = j + c - C0;
+            d = d < -ARX_BIAS_CENTER ? -ARX_BIAS_CENTER : (d > ARX_BIAS_CENTER ? ARX_BIAS_CENTER : d);
+            Bs[c * bst + attn_bias_off(c) + j] = bt[d];
+        }
+    }
+    __syncthreads();
+
+    AttnStream16 st;
+    st.qkv = qkv; st.cu = cu; st.ring = smem; st.H = H; st.h = h; st.G = G; st.n_seqs = n_seqs; st.ld = 3u * (uint32_t)H;
+    st.p_b = g_blk; st.p_t0 = 0; st.p_L = 0; st.p_step = 0; st.p_nqp = 0; st.p_nsteps = 0; st.p_slot = 0; st.c_slot = 0;
+    st.inflight = 0; st.pend_st = 0; st.st_bits = 0u;
+    st.p_load_item();
+    if (st.p_L == 0) return;
+#pragma unroll 1
+    for (int i = 0; i < R::AHEAD && st.p_L > 0; ++i) st.issue_next();
+
+    // ---- per-lane constants: query column qi = lane & 15, lane group g = lane >> 4
+    const int qi = lane & 15, g = lane >> 4;
+    // K / Q fragment (row qi of a 16-row block, 16-B chunk 4 ks + g, swizzled by the row): k0 ^ (ks << 6)
+    const int k0 = qi * ROWB + ((g ^ ((qi >> 1) & 7)) << 4);
+    // transposing read of V: lane 4 q' + p' of its 16-lane group addresses row 4 g + q', columns 16 db + 4 p' .. + 3
+    const int qp = qi >> 2, pp = qi & 3;
+    const int vrow = 4 * g + qp;
+    const uint32_t v0 = (uint32_t)(64 * ROWB + vrow * ROWB + ((((pp >> 1)) ^ (((vrow >> 1) & 3) << 1)) << 4) + ((pp & 1) << 3));
+    const float inv_scale = 1.0f / scale_log2e;
+
+    int b = g_blk;
+#pragma unroll 1
+    for (;;) {
+        int t0 = 0, L = 0;
+        while (b < n_seqs) {
+            const __attribute__((address_space(4))) int32_t* cuc = (const __attribute__((address_space(4))) int32_t*)cu;
+            t0 = cuc[b]; L = cuc[b + 1] - t0;
+            if (L > 0) break;
+            b += G;
+        }
+        if (b >= n_seqs) break;
+        const int nqp = L > 128 ? 2 : 1, nkv = (L + 63) >> 6, nkt = (L + 31) >> 5;
+        const bool wave_on = wid * 16 < L;
+        bf16x8 qf[2];
+        f32x4 o[4];
+        f32x4 lsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m_run = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[ks][e] = (bf16_t)0.f;
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int q = wid * 16 + qi, qc = q < L ? q : L - 1;
+        const int bc = (4 - (qc & 3)) & 3;
+        const float* bptr = Bs + bc * bst + attn_bias_off(bc) + (C0 - qc - bc) + 4 * g;
+
+#pragma unroll 1
+        for (int p = 0; p < nqp; ++p) {
+            const char* slot = st.step_begin();
+            if (wave_on && (wid >> 3) == p) {
+                const char* qrow = slot + (wid & 7) * 16 * ROWB;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + (k0 ^ (ks << 6)));
+            }
+        }
+        const bool ragged = (L & 31) != 0;
+#pragma unroll 1
+        for (int sidx = 0; sidx < nkv; ++sidx) {
+            const char* slot = st.step_begin();
+            if (wave_on) {
+#pragma unroll 1
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int kt = 2 * sidx + t2;
+                    if (kt >= nkt) break;
+                    const char* kbase = slot + t2 * 32 * ROWB;
+                    const bool msk = ragged && kt == nkt - 1;
+                    if (kt == 0) {
+                        if (msk) attn_ring16_tile<HAS_BIAS, true, true>(kbase, k0, v0, qf, o, lsum, m_run, bptr, kt, g, L, scale_log2e, inv_scale);
+                        else attn_ring16_tile<HAS_BIAS, false, true>(kbase, k0, v0, qf, o, lsum, m_run, bptr, kt, g, L, scale_log2e, inv_scale);
+                    } else {
+                        if (msk) attn_ring16_tile<HAS_BIAS, true, false>(kbase, k0, v0, qf, o, lsum, m_run, bptr + 32 * kt, kt, g, L, scale_log2e, inv_scale);
+                        else attn_ring16_tile<HAS_BIAS, false, false>(kbase, k0, v0, qf, o, lsum, m_run, bptr + 32 * kt, kt, g, L, scale_log2e, inv_scale);
+                    }
+                }
+            }
+        }
+        if (wave_on) {
+            // row sum over the four lane groups of the query, then normalise and store: lane holds O[q][16 db + 4 g .. + 3]
+            float l_tot = lsum[0];
+            {
+                const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+                l_tot = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+                const auto c2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_tot), __float_as_uint(l_tot), false, false);
+                l_tot = __uint_as_float(c2[0]) + __uint_as_float(c2[1]);
+            }
+            const float inv = 1.0f / l_tot;
+            uint16_t* orow = ctx + (int64_t)(t0 + qc) * H + h * 64 + 4 * g;
+            if (q < L) {
+#pragma unroll
+                for (int db = 0; db < 4; ++db) {
+                    u32x2 w2;
+                    w2[0] = pack_bf16x2(o[db][0] * inv, o[db][1] * inv);
+                    w2[1] = pack_bf16x2(o[db][2] * inv, o[db][3] * inv);
+                    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" :: "v"(orow + 16 * db), "v"(w2) : "memory");
+                }
+            }
+            st.pend_st += 4;
+        }
+        b += G;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Pool (masked mean over the sequence's tokens, or CLS row) + optional L2 normalise.
 // One block (256 thr) per sequence; writes f32 and/or fp16 rows.
 __global__ __launch_bounds__(256) void pool_norm_kernel(const uint16_t* __restrict__ x, const int32_t* __restrict__ cu,
@@ -965,14 +1264,25 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const uint16_t* __restri
     }
 }
 
-// Row statistics from the producers' partial slabs, added in fixed order: mean[m], rstd[m].
+// Row statistics from the producers' partial slabs, added in fixed order: mean[m], rstd[m].  NP = H / 64 partials per row and
+// statistic, all 2 NP loads of a thread in flight at once (the loop over a runtime count kept one pair in flight: 11 us per call
+// at 262 144 rows, 24 calls per forward).
+template <int NP>
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ ps, const float* __restrict__ pq, int64_t ld,
                                                            int nparts, const int32_t* __restrict__ n_rows_ptr, float inv_h, float eps,
                                                            float* __restrict__ mean, float* __restrict__ rstd) {
     const int m = blockIdx.x * 256 + threadIdx.x;
     if (m >= *n_rows_ptr) return;
     float s = 0.f, q = 0.f;
-    for (int p = 0; p < nparts; ++p) { s += ps[p * ld + m]; q += pq[p * ld + m]; }
+    if constexpr (NP > 0) {
+        float vs[NP], vq[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { vs[p] = ps[p * ld + m]; vq[p] = pq[p * ld + m]; }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { s += vs[p]; q += vq[p]; }
+    } else {
+        for (int p = 0; p < nparts; ++p) { s += ps[p * ld + m]; q += pq[p * ld + m]; }
+    }
     const float mu = s * inv_h;
     mean[m] = mu;
     rstd[m] = rsqrtf(fmaxf(q * inv_h - mu * mu, 0.f) + eps);

@@ -363,7 +363,7 @@ def test_full_size_properties(hip):
             assert rs[q, 9] - rs[q, 10] < 1e-6
 
 
-@pytest.mark.parametrize("attn", ["1", "2"])
+@pytest.mark.parametrize("attn", ["1", "2", "4"])
 @pytest.mark.parametrize("preset", ["all-mpnet-base-v2", "all-MiniLM-L6-v2"])
 def test_attention_block_forced_rescale(hip, preset, attn, monkeypatch):
     """The fused attention kernel alone on crafted q/k/v: (a) ordinary scores, (b) a late key whose score jumps far
@@ -443,7 +443,7 @@ def test_attention_ring_stream_many_items(hip, preset, monkeypatch):
     qd = q16.cuda().contiguous()
     dlens = torch.from_numpy(lens).cuda()
     outs = {}
-    for attn in ("1", "2"):
+    for attn in ("1", "2", "4"):
         monkeypatch.setenv("ARX_ATTN_VARIANT", attn)
         enc = HipEncoder(cfg, sd, max_tokens=T + 256, max_seqs=len(lens))
         res = []
@@ -457,10 +457,12 @@ def test_attention_ring_stream_many_items(hip, preset, monkeypatch):
         assert torch.equal(res[0].view(torch.int16), res[1].view(torch.int16)) and torch.equal(res[0].view(torch.int16), res[2].view(torch.int16))
         outs[attn] = res[0].float().cpu().numpy()
         enc.close()
-    assert np.isfinite(outs["2"]).all()
+    assert np.isfinite(outs["2"]).all() and np.isfinite(outs["4"]).all()
     scale = np.abs(q16.float().numpy()[:, 2 * H:]).max()
     assert np.abs(outs["2"] - outs["1"]).max() < 1.6e-2 * scale          # one bf16 ulp of the output at most (different row-sum rounding)
     assert (outs["2"] != outs["1"]).mean() < 0.02
+    assert np.abs(outs["4"] - outs["1"]).max() < 3.2e-2 * scale          # 16-query waves: other MFMA shape, other summation order
+    assert (outs["4"] != outs["1"]).mean() < 0.5
     x = q16.float().numpy().astype(np.float64)
     tbl = EO.toeplitz_bias_table(sd, cfg, 256)
     for b in (3, 4, 9, 14, 15, 40, 77, 311, 599):
@@ -476,8 +478,9 @@ def test_attention_ring_stream_many_items(hip, preset, monkeypatch):
                 sc = sc + tbl[hd][j - i + 255]
             sc -= sc.max(1, keepdims=True)
             pr = np.exp(sc); pr /= pr.sum(1, keepdims=True)
-            err = np.abs(outs["2"][cu[b]:cu[b + 1], hd * dh:(hd + 1) * dh] - pr @ v).max() / (np.abs(v).max() + 1e-9)
-            assert err < 2e-2, (b, hd, err)
+            for vv in ("2", "4"):
+                err = np.abs(outs[vv][cu[b]:cu[b + 1], hd * dh:(hd + 1) * dh] - pr @ v).max() / (np.abs(v).max() + 1e-9)
+                assert err < 2e-2, (vv, b, hd, err)
 
 
 def test_collection_query_shape_and_ranking(hip, tmp_path):
@@ -582,7 +585,7 @@ def test_gemm_counted_wait_schedule_race_screen(hip, variant):
         torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("env", [{"ARX_LN_FOLD": "0"}, {"ARX_ATTN_VARIANT": "0"}, {"ARX_ATTN_VARIANT": "1"}, {"ARX_ATTN_VARIANT": "2"},
+@pytest.mark.parametrize("env", [{"ARX_LN_FOLD": "0"}, {"ARX_ATTN_VARIANT": "0"}, {"ARX_ATTN_VARIANT": "1"}, {"ARX_ATTN_VARIANT": "2"}, {"ARX_ATTN_VARIANT": "4"},
                                  {"ARX_GEMM_VARIANT": "13"}, {"ARX_GEMM_VARIANT": "8"}, {"ARX_GEMM_VARIANT": "9"}])
 def test_alternative_schedules_agree(hip, golden_dir, env, monkeypatch):
     """The schedules shipped beside the default (explicit LayerNorm kernels, first attention kernel, 2-stage / per-tile /
