@@ -35,6 +35,7 @@ EXPORTS = {
     # name: (restype, argtypes)
     "arx_version": (C.c_int32, []),
     "arx_last_error": (C.c_char_p, []),
+    "arx_build_info": (C.c_int32, []),
     "arx_mpnet_bucket": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32]),
     "arx_encoder_workspace_bytes": (C.c_int64, [C.POINTER(EncoderConfigC), C.c_int32, C.c_int32]),
     "arx_encoder_create": (C.c_int32, [C.POINTER(EncoderConfigC), C.POINTER(EncoderWeightsC), C.c_int32, C.c_int32,

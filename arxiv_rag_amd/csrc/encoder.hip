@@ -413,6 +413,7 @@ static int launch_attn_tr_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream
     return ARX_OK;
 }
 
+#ifdef ARX_DEV_VARIANTS
 template <int DH, bool HB, int NSLOT>
 static int launch_attn_ring_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
     auto kern = attention_ring_kernel<DH, HB, NSLOT>;
@@ -443,15 +444,19 @@ static int launch_attn_ring16_cfg(arx_encoder* h, int n_seqs, int max_len, hipSt
     return ARX_OK;
 }
 
+#endif
+
 static int launch_attn(arx_encoder* h, int n_seqs, int max_len, hipStream_t st) {
     const int dh = h->cfg.hidden / h->cfg.heads;
     const bool hb = h->cfg.arch == ARX_ARCH_MPNET;
+#ifdef ARX_DEV_VARIANTS
     if (h->attn_variant == 4 && dh == 64 && max_len > 128 && max_len <= 256)      // 16-wave ring kernel (encoder_kernels.h "attention v4")
         return hb ? launch_attn_ring16_cfg<true>(h, n_seqs, max_len, st) : launch_attn_ring16_cfg<false>(h, n_seqs, max_len, st);
     if (h->attn_variant == 2 && max_len > 128 && max_len <= 256) {      // streaming ring kernel (encoder_kernels.h "attention v3"), one block per CU
         if (dh == 64) return hb ? launch_attn_ring_cfg<64, true, 8>(h, n_seqs, max_len, st) : launch_attn_ring_cfg<64, false, 8>(h, n_seqs, max_len, st);
         return hb ? launch_attn_ring_cfg<32, true, 8>(h, n_seqs, max_len, st) : launch_attn_ring_cfg<32, false, 8>(h, n_seqs, max_len, st);
     }
+#endif
     if (h->attn_variant >= 1) {      // transposing-read kernel; 8 waves cover 256 queries, 4 waves for short batches
         const bool w8 = max_len > 128;
         if (dh == 64) {
@@ -622,6 +627,14 @@ extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32
         ARX_HIP_CHECK(hipGetLastError());
     }
     return ARX_OK;
+}
+
+extern "C" int32_t arx_build_info(void) {
+#ifdef ARX_DEV_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" int32_t arx_adjacent_cosine(const float* emb, int64_t ld, int32_t n, int32_t dim, float* out, void* stream) {

@@ -559,6 +559,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     }
 }
 
+#ifdef ARX_DEV_VARIANTS
+// (dev build only: the two streaming attention kernels of round 2 — both correct and tested, both slower than v2 on this chip;
+//  DESIGN.md "attention: what the streaming kernels showed" has the numbers)
 // ---------------------------------------------------------------------------------------------------
 // attention v3 ("ring"): the same arithmetic as attention_tr_kernel, bit for bit — same tiles, same MFMA order, same lazy softmax
 // reference — under a different memory schedule.  The v2 kernel stages a whole (sequence, head) before its single barrier and
@@ -1186,6 +1189,8 @@ __global__ __launch_bounds__(1024, 4) void attention_ring16_kernel(const uint16_
         b += G;
     }
 }
+
+#endif  // ARX_DEV_VARIANTS
 
 // ---------------------------------------------------------------------------------------------------
 // Pool (masked mean over the sequence's tokens, or CLS row) + optional L2 normalise.

@@ -358,14 +358,23 @@ def save_embeddings_to_disk_fallback(chunks: List[Dict], embeddings: Sequence, o
 
 
 def _dump_metadata(chunks: List[Dict], path: Path):
-    meta = []
-    for i, ch in enumerate(chunks):
-        m = ch.get("metadata", {})
-        meta.append({"chunk_id": ch.get("chunk_id", f"chunk_{i}"), "paper_id": m.get("paper_id"),
-                     "section": m.get("section"), "quality_score": m.get("quality_score"),
-                     "text": ch["text"], "text_length": len(ch["text"])})
+    """metadata.json, byte for byte what `json.dump(metadata, f, indent=2, ensure_ascii=False)` writes at GEN:292-306, but
+    streamed one chunk at a time: the reference builds the whole list and its serialisation in RAM (the text of ~5 M chunks
+    twice over); here the peak is one entry."""
     with open(path, "w", encoding="utf-8") as fh:
-        json.dump(meta, fh, indent=2, ensure_ascii=False)
+        if not chunks:
+            fh.write("[]")
+            return
+        fh.write("[\n")
+        for i, ch in enumerate(chunks):
+            m = ch.get("metadata", {})
+            item = {"chunk_id": ch.get("chunk_id", f"chunk_{i}"), "paper_id": m.get("paper_id"),
+                    "section": m.get("section"), "quality_score": m.get("quality_score"),
+                    "text": ch["text"], "text_length": len(ch["text"])}
+            body = json.dumps(item, indent=2, ensure_ascii=False)
+            fh.write("  " + body.replace("\n", "\n  "))
+            fh.write(",\n" if i + 1 < len(chunks) else "\n")
+        fh.write("]")
 
 
 class MetadataPrefetch(threading.Thread):

@@ -124,6 +124,10 @@ int32_t arx_encoder_debug_hidden(arx_encoder* h, int32_t layer_slot, float* dst,
 /* Ask the next forward() to snapshot the hidden state after `layer` (-1 = off). */
 int32_t arx_encoder_set_tap(arx_encoder* h, int32_t layer);
 
+/* Build flags of the loaded library: bit 0 = built with -DARX_DEV_VARIANTS (the A/B schedules of DESIGN.md's negative-result
+ * tables are compiled in and selectable through ARX_GEMM_VARIANT / ARX_ATTN_VARIANT); 0 for the shipped build. */
+int32_t arx_build_info(void);
+
 /* ---- brute-force cosine top-k over an HBM-resident fp16 shard ------------------------------------
  *   corpus  device fp16 [n_rows, dim] row-major (unit rows => dot product = cosine), dim % 64 == 0
  *   queries device fp16 [n_queries, dim]
