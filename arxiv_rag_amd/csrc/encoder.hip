@@ -329,6 +329,10 @@ template <int MODE>
 static int launch_gemm(int cls, int variant, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int N, int K,
                        const EpiParams& ep, hipStream_t st) {
     ProfScope ps(cls, st);
+#ifdef ARX_DEV_VARIANTS
+    static const int dev_bw = getenv("ARX_DEV_BW") ? atoi(getenv("ARX_DEV_BW")) : 0;      // dev A/B in situ: tile-walk band width
+    if (dev_bw) { EpiParams e2 = ep; e2.dev_bw = dev_bw; return arx_launch_gemm<MODE>(variant, A, lda, W, ldw, M, N, K, e2, st); }
+#endif
     return arx_launch_gemm<MODE>(variant, A, lda, W, ldw, M, N, K, ep, st);
 }
 
@@ -340,6 +344,10 @@ extern "C" int32_t arx_gemm_bf16(const void* A, const void* W, const float* bias
     ARX_REQUIRE(mode != EPI_BIAS_RESID || resid, "mode 2 needs resid");
     EpiParams ep{(uint16_t*)C, N, bias, (const uint16_t*)resid, N};
     hipStream_t st = (hipStream_t)stream;
+#ifdef ARX_DEV_VARIANTS
+    // dev A/B encoding: variant = schedule + 100 * store mode (1 nt, 2 sc1) + 1000 * band width of the tile walk
+    ep.dev_store = (variant / 100) % 10; ep.dev_bw = variant / 1000; variant %= 100;
+#endif
 #ifdef ARX_STAMP
     {   // dev build: per-tile cycle stamps of one launch, summarised on stderr
         static unsigned long long* d = nullptr;

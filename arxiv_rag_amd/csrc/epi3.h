@@ -125,7 +125,15 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
             u32x4 o;
 #pragma unroll
             for (int pi = 0; pi < 4; ++pi) o[pi] = pack_bf16x2(vv[pi].x, vv[pi].y);
-            *reinterpret_cast<u32x4*>(p.out + (uint32_t)row_of(i) * (uint32_t)p.ldc + n0 + cb) = o;
+            {
+                u32x4* dst = reinterpret_cast<u32x4*>(p.out + (uint32_t)row_of(i) * (uint32_t)p.ldc + n0 + cb);
+#ifdef ARX_DEV_VARIANTS
+                if (p.dev_store == 1) __builtin_nontemporal_store(o, dst);
+                else if (p.dev_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(o) : "memory");
+                else
+#endif
+                    *dst = o;
+            }
             if constexpr (STATS) {
                 // statistics of the bf16-ROUNDED values (what the consumers will read back)
 #pragma unroll

@@ -211,6 +211,10 @@ struct EpiParams {
     float* o_sq = nullptr;          // [N/64][o_ld] partial sums of squares
     int64_t o_ld = 0;
     float inv_h = 0.f, eps = 0.f;
+#ifdef ARX_DEV_VARIANTS
+    int dev_store = 0;              // dev A/B: 0 plain stores, 1 non-temporal, 2 sc1 (write-through, line dropped from L2)
+    int dev_bw = 0;                 // dev A/B: band width of the tile walk in n-tiles (0 = TileWalk's own choice)
+#endif
 #ifdef ARX_STAMP
     unsigned long long* stamps = nullptr;   // dev build only: [tiles][4] s_memtime at start / loop entry / loop exit / end (wave 0)
 #endif

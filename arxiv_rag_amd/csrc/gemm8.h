@@ -31,15 +31,18 @@
 // contiguous range of m-panels (all their n-tiles) and walks it BAND by band: a band is `bw` adjacent n-tiles chosen so that the
 // band's slice of W (bw x 256 x K bf16) stays resident in the XCD's 4-MB L2 while the A panels stream through once per band;
 // inside a band the order is n-fastest, so the CUs of an XCD share both the A panel and the W slices they are reading.
-// Without bands (bw = tiles_n) FFN-1's 4.7-MB W and the A stream evict each other: 2.9 GB of L2 fills per launch against
-// 0.41 GB of operands (rocprofv3 FETCH_SIZE); with two bands of six the A operand is filled twice and W about once.
+// Without bands (bw = tiles_n) FFN-1's 4.7-MB W and the A stream evict each other: 2.7-2.9 GB of L2 fills per launch against
+// 0.41 GB of operands (rocprofv3 FETCH_SIZE); with two bands of six the A operand is filled twice and W about once (1.84 GB).
+// Fills are not time, though (round-2 A/B, profiles/r02/gemm_store_band_ab.json: the Infinity Cache serves them): FFN-1 runs the same
+// banded or not, and QKV (W = 3.5 MB, inside the L2) is 3 % FASTER unbanded at 1.8x the fills — so only a W beyond the L2 is banded.
 struct TileWalk {
     int tiles_m, tiles_n, bw;
-    __device__ __forceinline__ TileWalk(int tm, int tn, int K) : tiles_m(tm), tiles_n(tn) {
+    __device__ __forceinline__ TileWalk(int tm, int tn, int K, int bw_override = 0) : tiles_m(tm), tiles_n(tn) {
+        if (bw_override > 0) { bw = bw_override < tn ? bw_override : tn; return; }
         const int w_tile = 512 * K;                               // bytes of one n-tile's W slice
         const int total = tn * w_tile;
         bw = tn;
-        if (total > (5 << 19) && K <= 1024) {                     // > 2.5 MB and a small A operand: band it (~2.4 MB per band)
+        if (total > (4 << 20) && K <= 1024) {                     // W larger than the XCD's 4-MB L2 and a small A operand: band it (~2.4 MB per band)
             const int nb = (total + (12 << 18) / 5 * 4 - 1) / ((12 << 18) / 5 * 4);
             bw = (tn + nb - 1) / nb;
         }
@@ -211,7 +214,11 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
                                                            int M, int N, int K, int tiles_m, int tiles_n, EpiParams ep) {
     using ML = Gemm8Phase<bf16_t, KROT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef ARX_DEV_VARIANTS
+    const TileWalk walk(tiles_m, tiles_n, K, ep.dev_bw);
+#else
     const TileWalk walk(tiles_m, tiles_n, K);
+#endif
     int tile_m, tile_n;
     if (!walk.coords(blockIdx.x, tile_m, tile_n)) return;
     const int m0 = tile_m * 256, n0 = tile_n * 256;
@@ -258,7 +265,11 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
     const uint16_t* Wg = reinterpret_cast<const uint16_t*>(W);
     const int ntiles = tiles_m * tiles_n, stride = gridDim.x, nk = K >> 6;
 
+#ifdef ARX_DEV_VARIANTS
+    const TileWalk walk(tiles_m, tiles_n, K, ep.dev_bw);
+#else
     const TileWalk walk(tiles_m, tiles_n, K);
+#endif
     auto tile_of = [&](int o, int& m0, int& n0, int& ko) {
         int tm = 0, tn = 0;
         const bool ok = walk.coords(o, tm, tn);
