@@ -416,15 +416,19 @@ dist.destroy_process_group()
 '''
 
 
-def test_world_size_2_gloo_matches_single_process(tmp_path, tiny_model):
+@pytest.mark.parametrize("world", [2, 3])
+def test_world_size_2_gloo_matches_single_process(tmp_path, tiny_model, world):
+    """One process per rank (torchrun, gloo on CPU): every rank encodes, keeps and writes its own contiguous row range; the
+    three files must be the single-process run's, byte for byte; the search exchange (all_gather of partials + merge) equals the
+    global answer.  world = 3 splits the 5 quanta 2 / 2 / 1 (uneven shards)."""
     cfg, sd, tok = tiny_model
     make_chunk_tree(tmp_path / "in", n_files=6, chunks_per_file=5)
     (tmp_path / "w.py").write_text(_WORKER)
     (tmp_path / "out2").mkdir(); (tmp_path / "out1").mkdir()
     env = dict(os.environ, ARX_ROOT=str(ROOT), ARX_IN=str(tmp_path / "in"), ARX_OUT=str(tmp_path / "out2"),
                OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29617", str(tmp_path / "w.py")],
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                        "--master-addr", "127.0.0.1", "--master-port", str(29615 + world), str(tmp_path / "w.py")],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
     cwd = os.getcwd()
