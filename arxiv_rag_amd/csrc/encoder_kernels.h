@@ -457,15 +457,13 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     // (s0 = -m_run / scale), so fma(acc, scale, bias) already yields v - m_run and exp2 needs no subtraction; the
     // reference is only moved (and O, l rescaled) when some lane's tile maximum exceeds it by more than THR (base-2
     // units; P then stays <= 2^THR, exact up to the final normalisation).  Tile 0 always takes the exact-maximum path
-    // (no reference exists yet).  Row sums ride on the idle matrix pipe: l^T += ones . P^T (2 MFMAs per tile).
+    // (no reference exists yet).  Row sums ride on the matrix pipe: the 4x4x4 MFMA with A = ones adds each lane's own four bf16 B
+    // values into its accumulator (4 registers and 4 x 8 cycles per tile; the 32x32x16 form of round 1 took 16 registers and 64
+    // cycles to compute the same sum in every row); the two lane halves of a query are added once, at the end.
     constexpr float THR = 8.0f;
     const float inv_scale = 1.0f / scale_log2e;
-    f32x16 lacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+    f32x4 lsum = f32x4{0.f, 0.f, 0.f, 0.f};
+    const s16x4 one4 = s16x4{0x3f80, 0x3f80, 0x3f80, 0x3f80};
     auto tile = [&](auto masked_tag, auto first_tag, int kt) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -502,7 +500,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
             const float alpha = __builtin_amdgcn_exp2f(-d);
             m_run += d;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] -= d; lacc[r] *= alpha; }
+            for (int r = 0; r < 16; ++r) s[r] -= d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lsum[r] *= alpha;
 #pragma unroll
             for (int dd = 0; dd < DB; ++dd)
 #pragma unroll
@@ -510,13 +510,15 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+        uint32_t pw[8];                                       // P as bf16, one v_cvt_pk_bf16_f32 per pair
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pw[j] = pack_bf16x2(s[2 * j], s[2 * j + 1]);
         bf16x8 pf[2];
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss)
+        for (int ss = 0; ss < 2; ++ss) pf[ss] = __builtin_bit_cast(bf16x8, u32x4{pw[4 * ss], pw[4 * ss + 1], pw[4 * ss + 2], pw[4 * ss + 3]});
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pf[ss][e] = (bf16_t)s[8 * ss + e];
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[ss], lacc, 0, 0, 0);
+        for (int j = 0; j < 4; ++j)
+            lsum = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, __builtin_bit_cast(s16x4, u32x2{pw[2 * j], pw[2 * j + 1]}), lsum, 0, 0, 0);
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
 #pragma unroll
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     for (int kt = 1; kt < nfull; ++kt) tile(std::false_type{}, std::false_type{}, kt);
     if (nfull < nkt && nkt > 1) tile(std::true_type{}, std::false_type{}, nkt - 1);
 
-    const float l_tot = lacc[0];                           // every accumulator row holds the same sum over all keys
+    const float l_tot = lsum[0] + __shfl_xor(lsum[0], 32);  // the two lane halves hold disjoint keys of the same query
     (void)l_run;
     const float inv = 1.0f / l_tot;
     if (q < L) {
