@@ -214,6 +214,28 @@ def cpu_baseline(model_name, cfg, sd, S, budget_s=30.0):
         out["sample"] = f"leg {best} (best of A/C): " + L["what"] + f"; host: {os.cpu_count()} logical cpus, {eff} usable by this job"
     else:                                                    # both stand-ins failed: fall back to the numpy restatement's number
         out["value"], out["cores"], out["sample"] = out["numpy_oracle"]["value"], eff, out["numpy_oracle"]["what"]
+    # the search step on the same cores (BASELINE.md CPU-S): the definitional oracle (fp32 matmul on the fp16-rounded rows + exact
+    # top-10), 256 queries over a 100 k-row sample of the 10 M-row workload; the scan is linear in the rows, so the 10 M figure is
+    # the measured one / 100 (stated as scaled)
+    try:
+        from oracle import search_oracle as SO
+        try:
+            from threadpoolctl import threadpool_limits
+            lim2 = threadpool_limits(limits=eff)
+        except Exception:
+            lim2 = None
+        n_s, nq_s, d_s = 100_000, 256, cfg.hidden
+        Cs = SO.unit_rows_f16(n_s, d_s, 7); Qs = SO.unit_rows_f16(nq_s, d_s, 11)
+        SO.topk_search(Cs[:20000], Qs, 10)
+        t0 = time.time(); SO.topk_search(Cs, Qs, 10); ts = time.time() - t0
+        if lim2 is not None:
+            lim2.restore_original_limits()
+        out["search"] = {"qps_at_sample": round(nq_s / ts, 1), "qps_scaled_to_10M_rows": round(nq_s / ts * n_s / 10_000_000, 2),
+                         "unit": "queries/s", "threads": eff,
+                         "what": f"oracle/search_oracle.py (numpy fp32 Q @ C.T + exact top-10), {nq_s} queries x {n_s} x {d_s} fp16 rows, "
+                                 f"{ts:.1f} s; scaled linearly in the row count"}
+    except Exception as e:                                   # noqa: BLE001
+        out["search"] = {"error": repr(e)[:200]}
     return out
 
 
