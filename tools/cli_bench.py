@@ -34,8 +34,12 @@ with tempfile.TemporaryDirectory() as td:
     os.chdir(td)
     buf = io.StringIO()
     t0 = time.time()
+    argv = [str(tree), "--min-quality", "0.9", "--skip-chroma"]
+    if os.environ.get("CLI_QUERIES"):             # also run the added search step over the shard the encode step leaves in HBM
+        (td / "queries.txt").write_text("\n".join(" ".join(rs.choice(words, size=12)) for _ in range(int(os.environ["CLI_QUERIES"]))) + "\n")
+        argv += ["--queries", str(td / "queries.txt")]
     with contextlib.redirect_stdout(buf):
-        rc = GEN.main([str(tree), "--min-quality", "0.9", "--skip-chroma"], model_factory=lambda name: model)
+        rc = GEN.main(argv, model_factory=lambda name: model)
     dt = time.time() - t0
     out = buf.getvalue()
     n = n_files * cpf
@@ -44,4 +48,4 @@ with tempfile.TemporaryDirectory() as td:
     print(json.dumps({"rc": rc, "chunks": n, "total_s": round(dt, 2), "chunks_per_s_whole_script": round(n / dt, 1),
                       "load_s": float(stages.get("Loading", 0)), "embed_s": float(stages.get("Embedding generation", 0)),
                       "write_s": round(dt - float(stages.get("Loading", 0)) - float(stages.get("Embedding generation", 0)), 2),
-                      "npy": [str(arr.dtype), list(arr.shape)]}))
+                      "npy": [str(arr.dtype), list(arr.shape)], "search_step": bool(os.environ.get("CLI_QUERIES"))}))
