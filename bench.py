@@ -267,7 +267,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is created whatever the world size, so that a 1-rank launch
+    # exercises exactly the code an N-rank launch runs: RCCL init, barrier, MAX all-reduce of the time, all-gather of partial top-k
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
@@ -275,7 +278,7 @@ def main():
     torch.cuda.set_device(dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -313,7 +316,7 @@ def main():
         step(W + i, i)
     barrier()
     _lib.prof_enable(False)
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -367,7 +370,7 @@ def main():
         ev[nb].record()
         barrier()
         dts = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             tm = torch.tensor([dts], dtype=torch.float64, device=dev); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dts = float(tm.item())
         first_n, last_n = min(100, nb), nb - max(nb - 100, 0)
         nrm = big[-min(B, total):].float().norm(dim=1)
@@ -399,7 +402,7 @@ def main():
                 s_, i_ = idx.search_distributed(queries[q0:q0 + qb], 10)
             barrier(); dts = time.perf_counter() - t0
             _lib.prof_enable(False)
-            if world > 1:
+            if use_dist:
                 tm = torch.tensor([dts], dtype=torch.float64, device=dev); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dts = float(tm.item())
             p = _lib.prof_read()
             gms, gn = p["search_groupmax"]
@@ -438,7 +441,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "encode": encode, "search": search,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
