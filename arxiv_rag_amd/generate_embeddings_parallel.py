@@ -465,33 +465,21 @@ def store_in_chroma_batched(chunks: List[Dict], embeddings: Sequence, db_path: s
 
 
 # --------------------------------------------------------------------------------------------- search (added step)
-def search_queries(model, chunks: List[Dict], shard, queries: List[str], top_k: int = 10,
-                   output_dir: str = "./embeddings_saved", local_range: Optional[Tuple[int, int]] = None) -> List[Dict]:
+def search_queries(model, chunks: List[Dict], shard: "ShardSink", queries: List[str], top_k: int = 10,
+                   output_dir: str = "./embeddings_saved") -> List[Dict]:
     """Brute-force cosine top-k (config.yaml:63-64 `top_k: 10`) over the rank's fp16 rows in HBM; with
     torchrun each rank holds the contiguous row shard it encoded and the partial top-k lists are
-    all-gathered over RCCL and merged.  `shard` is the `ShardSink` the encode step filled (rows [lo, hi) already in HBM:
-    nothing is uploaded here); a host matrix is also accepted for callers that only have the `.npy` rows (it is uploaded
-    once — `store.HipCollection` is the API meant for that)."""
+    all-gathered over RCCL and merged.  `shard` is the `ShardSink` the encode step filled: rows [lo, hi) are already where they
+    will be searched and nothing is uploaded here; the queries are encoded straight into an fp16 device matrix.  (A consumer that
+    only has the `.npy` rows on disk builds a `store.HipCollection` instead.)"""
     import torch
-    from .index import ShardIndex, shard_bounds
+    from .index import ShardIndex
     dist = _dist()
-    world = dist.get_world_size() if dist else 1
     rank = dist.get_rank() if dist else 0
     dev = model.encoder.device
-    if isinstance(shard, ShardSink):
-        lo, rows = shard.lo, shard.rows
-    else:
-        if local_range is not None:                   # `shard` already holds only this rank's rows [lo, hi)
-            lo, hi = local_range
-            local = shard
-        else:
-            lo, hi = shard_bounds(len(shard), world, rank)
-            local = shard[lo:hi]
-        rows = torch.from_numpy(np.ascontiguousarray(np.asarray(local, dtype=np.float16))).to(dev) if hi > lo else \
-            torch.empty((0, model.get_sentence_embedding_dimension()), dtype=torch.float16, device=dev)
     qd = torch.empty((len(queries), model.get_sentence_embedding_dimension()), dtype=torch.float16, device=dev)
     model.encode(queries, batch_size=256, normalize_embeddings=True, convert_to_numpy=True, device_f16_out=qd)
-    s, i = ShardIndex(rows, idx_base=lo).search_distributed(qd, top_k)
+    s, i = ShardIndex(shard.rows, idx_base=shard.lo).search_distributed(qd, top_k)
     s, i = s.cpu().numpy(), i.cpu().numpy()
     results = []
     for qi, text in enumerate(queries):
@@ -583,7 +571,6 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
             meta_prefetch = MetadataPrefetch(chunks, "./embeddings_saved")
             meta_prefetch.start()
         t0 = time.time()
-        local_range = None
         qs = []
         if args.queries:
             qs = [ln.strip() for ln in Path(args.queries).read_text(encoding="utf-8").splitlines() if ln.strip()]
@@ -592,7 +579,6 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
         if world > 1:
             # one process per GPU: every rank encodes, keeps and writes its own contiguous row range
             embeddings, lo, hi = generate_embeddings_sharded(chunks, args.model, args.batch_size, args.chunks_per_worker, sink=sink)
-            local_range = (lo, hi)
         else:
             embeddings = generate_embeddings_parallel(chunks, model_name=args.model, batch_size=args.batch_size,
                                                       num_workers=args.embedding_workers, chunks_per_worker=args.chunks_per_worker,
@@ -609,7 +595,10 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
             print()
         meta_prefetch = None
         if qs:
-            search_queries(_model, chunks, sink if sink is not None else embeddings, qs, top_k=args.top_k, local_range=local_range)
+            if sink is None:
+                print("⚠️  --queries needs the HIP encoder (the search step runs over the shard it leaves in HBM): skipped")
+            else:
+                search_queries(_model, chunks, sink, qs, top_k=args.top_k)
         store_time = 0.0
         if rank == 0 and not args.skip_chroma:
             try:

@@ -435,7 +435,7 @@ def main():
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"configs[1]: {args.model} shape, {B} chunks x {S} token ids per step per GPU, "
-                                   f"encode-only (embed+{cfg.layers} layers+mean-pool+L2 -> fp16 corpus rows)",
+                                   f"encode-only (embed+{cfg.layers} layers+{'CLS' if cfg.pool == C.POOL_CLS else 'mean'}-pool+L2 -> fp16 corpus rows)",
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "weights": "seeded N(0,0.02^2), seed 0"},
             "roofline": roofline, "cpu_baseline": cpu, "encode": encode, "search": search,

@@ -199,10 +199,13 @@ def test_sharded_branch_single_rank_nccl(nccl_world1, tmp_path, monkeypatch):
     meta = json.loads((tmp_path / "embeddings_saved" / "metadata.json").read_text())
     assert [m["chunk_id"] for m in meta] == [c["chunk_id"] for c in chunks]
     r_dev = GEN.search_queries(model, chunks, sink, qs, top_k=10, output_dir=str(tmp_path / "embeddings_saved"))
-    r_host = GEN.search_queries(model, chunks, rows, qs, top_k=10, output_dir=str(tmp_path / "embeddings_saved"), local_range=(lo, hi))
-    assert r_dev == r_host                                                                     # results unchanged by where the shard came from
     qd = torch.empty((len(qs), 384), dtype=torch.float16, device="cuda")
     model.encode(qs, normalize_embeddings=True, device_f16_out=qd)
+    # results unchanged by where the shard came from: the same search over the rows of the .npy file, uploaded here by the test
+    from arxiv_rag_amd.index import ShardIndex
+    s_up, i_up = ShardIndex(torch.from_numpy(arr.astype(np.float16)).cuda(), idx_base=lo).search_distributed(qd, 10)
+    assert [[h["index"] for h in r["results"]] for r in r_dev] == i_up.cpu().tolist()
+    assert np.array_equal(np.array([[h["score"] for h in r["results"]] for r in r_dev], np.float32), s_up.cpu().numpy())
     rs, ri = SO.topk_search(rows.astype(np.float16), qd.cpu().numpy(), 11)
     for qi, r in enumerate(r_dev):
         got = [h["index"] for h in r["results"]]
