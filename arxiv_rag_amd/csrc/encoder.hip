@@ -47,6 +47,8 @@ struct arx_encoder {
     float *part_s = nullptr, *part_q = nullptr;                                              // [H/64][tok_pad] partial slabs
     int variant = 89;
     int attn_variant = 1;
+    int attn_dev_word = 0;                        // dev: probes of attention_tr_kernel (0 in the product path)
+    unsigned long long* attn_stamps = nullptr;    // dev: per-block time stamps
 };
 
 struct WsLayout {
@@ -416,7 +418,7 @@ static int launch_attn_tr_cfg(arx_encoder* h, int n_seqs, int max_len, hipStream
     const float scale_log2e = 1.4426950408889634f / sqrtf((float)DH);
     dim3 grid(cdiv(max_len, 32 * NW), h->cfg.heads, n_seqs);
     ProfScope ps(ARX_K_ATTENTION, st);
-    kern<<<grid, NW * 64, smem, st>>>(h->qkv, h->ctx, h->cu, h->bias_tbl, h->cfg.hidden, scale_log2e);
+    kern<<<grid, NW * 64, smem, st>>>(h->qkv, h->ctx, h->cu, h->bias_tbl, h->cfg.hidden, scale_log2e, h->attn_dev_word, h->attn_stamps);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -636,6 +638,15 @@ extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32
     }
     return ARX_OK;
 }
+
+#ifdef ARX_DEV_VARIANTS
+// dev build only (not in include/arx.h): probe word and per-block stamp buffer (4 x u64 per block) of attention_tr_kernel
+extern "C" int32_t arx_dev_attn_set(arx_encoder* h, int32_t word, void* stamps) {
+    h->attn_dev_word = word;
+    h->attn_stamps = (unsigned long long*)stamps;
+    return ARX_OK;
+}
+#endif
 
 extern "C" int32_t arx_build_info(void) {
 #ifdef ARX_DEV_VARIANTS

@@ -342,7 +342,9 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(const uint16_t* __re
 //     16s+8+4hh.. at this lane's dh column) — no b16 scatter while staging;
 //   * NW = 8 waves x 32 queries: one block covers a whole 256-token sequence-head, K/V staged once;
 //   * the key mask is applied only in the (uniform) ragged last tile; O is rescaled only when some lane's
-//     running max moved.
+//     running max moved;
+//   * (round 2) the tile loop that normally runs is the OPTIMISTIC one — fixed softmax reference 0, hand-pipelined LDS reads —
+//     and the running-maximum loop is its range-checked fallback (see the kernel body).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int DH> struct AttnSmem2 {
     static __host__ __device__ int kv_bytes(int Lk) { return Lk * DH * 2; }
@@ -363,10 +365,20 @@ template <int DH, bool HAS_BIAS, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ ctx,
                                                                         const int32_t* __restrict__ cu,
                                                                         const float* __restrict__ bias_tbl, int H,
-                                                                        float scale_log2e) {
+                                                                        float scale_log2e, int dev_word, unsigned long long* dev_stamps) {
+    // dev_word / dev_stamps: 0 / nullptr in the product path.  The dev build (tools/attn_probe.py) uses them for per-block time
+    // stamps (start, barrier passed, slowest wave's end, hardware id) and for two probes: word 3 = staging only, 5 = compute only,
+    // 6 = the exact (running-maximum) tile loop instead of the optimistic one.
     constexpr int NT = NW * 64;
     constexpr int CPR = DH / 8;
     constexpr int RPB = 256 / (DH * 2);
+#ifdef ARX_DEV_VARIANTS
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (dev_stamps && threadIdx.x == 0) {
+        dev_stamps[4 * lin] = wall_clock64();
+        dev_stamps[4 * lin + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    }
+#endif
     constexpr int KS = DH / 16;
     constexpr int DB = DH / 32;
     constexpr int ROWB = DH * 2;                  // bytes per K / V row in LDS
@@ -410,7 +422,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
         const int kc = pc ^ ((r0 / RPB) & (CPR - 1));
         const int vc = (DH == 64) ? (pc ^ (((r0 >> 1) & 1) << 2)) : pc;
         uint32_t lo = (uint32_t)(tid & ~63) * 16;
-        for (int row = r0; row < Lk; row += RPI, lo += NT * 16) {
+        int LkS = Lk;
+#ifdef ARX_DEV_VARIANTS
+        if (dev_word == 5) LkS = 0;                        // probe: compute only (LDS holds whatever it holds)
+#endif
+        for (int row = r0; row < LkS; row += RPI, lo += NT * 16) {
             const uint32_t gr = (uint32_t)(row < L ? row : L - 1) * ld;
             __builtin_amdgcn_global_load_lds((gbl_v*)(Kg + gr + kc * 8), (lds_v*)(Ks + lo), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gbl_v*)(Vg + gr + vc * 8), (lds_v*)(Vs + lo), 16, 0, 0);
@@ -420,39 +436,181 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
         const float* bt = bias_tbl + (int64_t)h * ARX_BIAS_ROW + ARX_BIAS_CENTER;
         const int span = 2 * Lk + 8;
         for (int i = tid; i < 4 * span; i += NT) {
-            const int c = i / span, j = i - c * span;
+            const int c = (i >= span) + (i >= 2 * span) + (i >= 3 * span), j = i - c * span;      // i / span without the software division
             int d = j + c - Lk;
             d = d < -ARX_BIAS_CENTER ? -ARX_BIAS_CENTER : (d > ARX_BIAS_CENTER ? ARX_BIAS_CENTER : d);
             Bs[c * bst + attn_bias_off(c) + j] = bt[d];
         }
     }
     __syncthreads();
+#ifdef ARX_DEV_VARIANTS
+    if (dev_stamps && threadIdx.x == 0) dev_stamps[4 * lin + 1] = wall_clock64();
+    if (dev_word == 3) {                                   // probe: staging only (a never-taken store keeps the Q loads alive)
+        if (q < L && qf[0][0] == 0x7fc1 && qf[1 % KS][1] == 0x7fc2) ctx[(int64_t)(t0 + q) * H + h * DH] = 1;
+        return;
+    }
+#endif
 
     if (qw >= L) return;
     f32x16 o[DB];
+    // LDS read bases of this lane (a tile's reads are base + 32-key tile offset + constant); recomputed by whichever pass runs, so that
+    // the optimistic loop does not carry the fallback's copies through its 128-register budget
+    auto lds_bases = [&](const float*& bb, const char* (&kb)[KS], const char* (&vb)[DB]) {
+        const int bc = (4 - (qc & 3)) & 3;
+        bb = Bs + bc * bst + attn_bias_off(bc) + (Lk - qc - bc) + 4 * hh;
+        const int krow_sw = ((ql / RPB) & (CPR - 1));
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kb[ks] = Ks + ql * ROWB + (((2 * ks + hh) ^ krow_sw) << 4);
+        const int g16 = lane >> 4, q_ = (lane & 15) >> 2, p_ = lane & 3;
+        const int vsw = (DH == 64) ? (((q_ >> 1) & 1) << 2) : 0;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+            const int col = 32 * d + 16 * (g16 & 1) + 4 * p_;
+            vb[d] = Vs + (4 * hh + q_) * ROWB + (((col >> 3) ^ vsw) << 4) + ((p_ & 1) << 3);
+        }
+    };
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    f32x4 lsum;
+    const s16x4 one4 = s16x4{0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    const int nkt = Lk >> 5;
+    const int nfull = (L & 31) ? nkt - 1 : nkt;           // tiles with no masked key
+    float l_tot;
+
+    // OPTIMISTIC pass: softmax with the FIXED reference 0 — P = exp2(v) straight from the scaled, biased score, no running maximum, no
+    // accumulator pre-load, no cross-lane exchange, no rescaling: per 32-key tile that removes 16 v_mov, 16 max, a ds_bpermute round
+    // trip and a branch from the ~135 vector instructions of the exact tile below (85 remain).  fp32 and bf16 share an 8-bit exponent,
+    // so P, the row sum and O keep their relative precision at any magnitude; what a fixed reference cannot do is keep them in RANGE.
+    // The pass is therefore accepted only if every row sum of the wave ended inside [2^-100, 2^100] (with |V| < 2^27 nothing overflowed on
+    // the way; an inf / NaN / fully underflowed row fails the test) — otherwise the wave redoes its queries with the exact loop.  Scores of
+    // real encoders sit within +-30 base-2 units; tests/test_gpu_parity.py drives both outcomes.
+    // What it buys is modest (0.415 -> 0.40 ms at 1024 x 256 tokens, tools/attn_probe.py): with the tile loop emptied out entirely the
+    // launch still takes 0.33 ms (staging alone 0.215 ms) — the kernel is bound by what a CU can take in and put out per block
+    // (96 KB in, 32 KB out, ~12.5 B/clk/CU = the chip's 6.4 TB/s), not by its arithmetic.
+    bool redo = false;
+#ifdef ARX_DEV_VARIANTS
+    redo = dev_word == 6;
+#endif
+    if (!redo) {
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+        lsum = f32x4{0.f, 0.f, 0.f, 0.f};
+        typedef const __attribute__((address_space(3))) char* lds_cptr;      // 32-bit LDS pointers: one VGPR each, no flat-address casts in the loop
+        typedef const __attribute__((address_space(3))) float* lds_fptr;
+        lds_fptr bp;
+        lds_cptr kp[KS], vp[DB];
+        {
+            const float* bb;
+            const char* kb[KS];
+            const char* vb[DB];
+            lds_bases(bb, kb, vb);
+            bp = (lds_fptr)bb;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kp[ks] = (lds_cptr)kb[ks];
+#pragma unroll
+            for (int d = 0; d < DB; ++d) vp[d] = (lds_cptr)vb[d];
+        }
+        // One tile, software-pipelined by hand (sched_barrier pins the stage order; the waits hipcc inserts are counted, LDS returns in
+        // order).  Left to itself hipcc issues every LDS read right before its use — twelve exposed LDS round trips per tile and wave
+        // (tools/attn_probe.py).  Here every read is issued a stage ahead of its use:
+        //   S = K(t) Q^T (K fragments requested during tile t-1) | bias rows(t), V^T fragments(t) | exp2 / pack | K fragments(t+1) | row sums, PV
+        // Tiles go in pairs: the second tile's reads are immediate offsets of the first's address registers, which advance once per pair.
+        bf16x8 kf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kp[ks]);
+        auto advance = [&](int n) {
+            bp += 32 * n;
+            asm volatile("" : "+v"(bp));                       // opaque: otherwise the loop passes rewrite the seven addresses as base + induction
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { kp[ks] += 32 * ROWB * n; asm volatile("" : "+v"(kp[ks])); }      // variable and copy each one
+#pragma unroll
+            for (int d = 0; d < DB; ++d) { vp[d] += 32 * ROWB * n; asm volatile("" : "+v"(vp[d])); }           // (v_add 0) per use: +7 registers
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto fast = [&](auto masked_tag, auto off_tag, int kt) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            constexpr int OFF = decltype(off_tag)::value;      // tile inside the pair
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;           // a constant-zero C operand: no register initialisation
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 bv[4];                                       // requested behind the S MFMAs: their 4 x 32 cycles cover the LDS round trip
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) bv[g4] = HAS_BIAS ? *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(bp + OFF * 32 + 8 * g4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            s16x4 vt[DB][4];
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) vt[d][j] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp[d] + (OFF * 32 + 8 * j) * ROWB));
+            __builtin_amdgcn_sched_barrier(0);
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 sc2 = f32x2{scale_log2e, scale_log2e};
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {               // v_pk_fma_f32: two scores per instruction
+                    f32x2 v = __builtin_elementwise_fma(f32x2{s[g4 * 4 + e], s[g4 * 4 + e + 1]}, sc2, f32x2{bv[g4][e], bv[g4][e + 1]});
+                    if (MASKED) {
+                        v[0] = (kt * 32 + 8 * g4 + 4 * hh + e < L) ? v[0] : -INFINITY;
+                        v[1] = (kt * 32 + 8 * g4 + 4 * hh + e + 1 < L) ? v[1] : -INFINITY;
+                    }
+                    s[g4 * 4 + e] = v[0]; s[g4 * 4 + e + 1] = v[1];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+            uint32_t pw[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pw[j] = pack_bf16x2(s[2 * j], s[2 * j + 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!MASKED) {                                     // after the last K tile this reads the head of V: in bounds, unused
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) kf[ks] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(kp[ks] + (OFF + 1) * 32 * ROWB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 pf[2];
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) pf[ss] = __builtin_bit_cast(bf16x8, u32x4{pw[4 * ss], pw[4 * ss + 1], pw[4 * ss + 2], pw[4 * ss + 3]});
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                lsum = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(one4, __builtin_bit_cast(s16x4, u32x2{pw[2 * j], pw[2 * j + 1]}), lsum, 0, 0, 0);
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int ss = 0; ss < 2; ++ss) {
+                    s16x8 v8;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v8[e] = vt[d][2 * ss][e]; v8[4 + e] = vt[d][2 * ss + 1][e]; }
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v8), pf[ss], o[d], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int kt = 0;
+        for (; kt + 2 <= nfull; kt += 2) {
+            fast(std::false_type{}, std::integral_constant<int, 0>{}, kt);
+            fast(std::false_type{}, std::integral_constant<int, 1>{}, kt + 1);
+            advance(2);
+        }
+        if (kt < nfull) { fast(std::false_type{}, std::integral_constant<int, 0>{}, kt); advance(1); }
+        if (nfull < nkt) fast(std::true_type{}, std::integral_constant<int, 0>{}, nkt - 1);
+        l_tot = lsum[0] + __shfl_xor(lsum[0], 32);         // the two lane halves hold disjoint keys of the same query
+        redo = !__all(l_tot > 0x1p-100f && l_tot < 0x1p100f);
+    }
+    if (redo) {
+    // EXACT pass (the wave's fallback; wave-uniform branch)
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    // running LDS pointers, advanced by one 32-key tile per iteration; every read below is base + constant
-    const int bc = (4 - (qc & 3)) & 3;
-    const float* bptr = Bs + bc * bst + attn_bias_off(bc) + (Lk - qc - bc) + 4 * hh;
-    const int krow_sw = ((ql / RPB) & (CPR - 1));
+    float m_run = -INFINITY;
+    const float* bptr;
     const char* kptr[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kptr[ks] = Ks + ql * ROWB + (((2 * ks + hh) ^ krow_sw) << 4);
-    const int g16 = lane >> 4, q_ = (lane & 15) >> 2, p_ = lane & 3;
-    const int vsw = (DH == 64) ? (((q_ >> 1) & 1) << 2) : 0;
     const char* vptr[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d) {
-        const int col = 32 * d + 16 * (g16 & 1) + 4 * p_;
-        vptr[d] = Vs + (4 * hh + q_) * ROWB + (((col >> 3) ^ vsw) << 4) + ((p_ & 1) << 3);
-    }
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-
+    lds_bases(bptr, kptr, vptr);
     // Online softmax with a LAZY reference: the running reference m_run is folded into the S accumulator's initial value
     // (s0 = -m_run / scale), so fma(acc, scale, bias) already yields v - m_run and exp2 needs no subtraction; the
     // reference is only moved (and O, l rescaled) when some lane's tile maximum exceeds it by more than THR (base-2
@@ -462,8 +620,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     // cycles to compute the same sum in every row); the two lane halves of a query are added once, at the end.
     constexpr float THR = 8.0f;
     const float inv_scale = 1.0f / scale_log2e;
-    f32x4 lsum = f32x4{0.f, 0.f, 0.f, 0.f};
-    const s16x4 one4 = s16x4{0x3f80, 0x3f80, 0x3f80, 0x3f80};
+    lsum = f32x4{0.f, 0.f, 0.f, 0.f};
     auto tile = [&](auto masked_tag, auto first_tag, int kt) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -538,14 +695,12 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
 #pragma unroll
         for (int d = 0; d < DB; ++d) vptr[d] += 32 * ROWB;
     };
-    const int nkt = Lk >> 5;
-    const int nfull = (L & 31) ? nkt - 1 : nkt;           // tiles with no masked key
     if (nfull > 0) tile(std::false_type{}, std::true_type{}, 0); else tile(std::true_type{}, std::true_type{}, 0);
     for (int kt = 1; kt < nfull; ++kt) tile(std::false_type{}, std::false_type{}, kt);
     if (nfull < nkt && nkt > 1) tile(std::true_type{}, std::false_type{}, nkt - 1);
+    l_tot = lsum[0] + __shfl_xor(lsum[0], 32);
+    }
 
-    const float l_tot = lsum[0] + __shfl_xor(lsum[0], 32);  // the two lane halves hold disjoint keys of the same query
-    (void)l_run;
     const float inv = 1.0f / l_tot;
     if (q < L) {
         uint16_t* orow = ctx + (int64_t)(t0 + q) * H + h * DH;
@@ -559,6 +714,9 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
                 *reinterpret_cast<u32x2*>(orow + d * 32 + 8 * g4 + 4 * hh) = w2;
             }
     }
+#ifdef ARX_DEV_VARIANTS
+    if (dev_stamps && (threadIdx.x & 63) == 0) atomicMax(&dev_stamps[4 * lin + 2], (unsigned long long)wall_clock64());
+#endif
 }
 
 #ifdef ARX_DEV_VARIANTS
