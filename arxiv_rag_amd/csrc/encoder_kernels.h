@@ -456,6 +456,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     // LDS read bases of this lane (a tile's reads are base + 32-key tile offset + constant); recomputed by whichever pass runs, so that
     // the optimistic loop does not carry the fallback's copies through its 128-register budget
     auto lds_bases = [&](const float*& bb, const char* (&kb)[KS], const char* (&vb)[DB]) {
+        int lane = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane));                  // opaque: a pass derives its addresses from scratch, nothing is shared (and kept live)
+        const int ql = lane & 31, hh = lane >> 5;
+        int qc = q0 + wid * 32 + ql;
+        qc = qc < L ? qc : L - 1;
         const int bc = (4 - (qc & 3)) & 3;
         bb = Bs + bc * bst + attn_bias_off(bc) + (Lk - qc - bc) + 4 * hh;
         const int krow_sw = ((ql / RPB) & (CPR - 1));
