@@ -45,6 +45,7 @@ EXPORTS = {
                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
     "arx_encoder_attention": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "arx_encoder_set_tap": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "arx_encoder_set_low_latency": (C.c_int32, [C.c_void_p, C.c_int32]),
     "arx_encoder_debug_hidden": (C.c_int32, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "arx_topk_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "arx_topk_search": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

@@ -3,12 +3,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "arx_common.h"
 #include "encoder_kernels.h"
 #include "gemm.h"
 #include "gemm8.h"
+#include "gemm_small.h"
 
 // MPNet / T5 bidirectional bucket (TF modeling_mpnet.py:330-349). rel = key_pos - query_pos.
 // Integer-exact restatement: the float32 expression there lands on the expected side of every
@@ -46,6 +48,8 @@ struct arx_encoder {
     float *st1_sum = nullptr, *st1_sq = nullptr, *st2_sum = nullptr, *st2_sq = nullptr;   // row mean / rstd of y1 / y2
     float *part_s = nullptr, *part_q = nullptr;                                              // [H/64][tok_pad] partial slabs
     int variant = 89;
+    int low_latency = 0;                          // arx_encoder_set_low_latency: forwards of <= ARX_SMALL_M rows take gemm_small.h
+    float* small_ws = nullptr;                    // its split-K partial sums (ARX_SMALL_WS_BYTES, allocated when the option is first set)
     int attn_variant = 1;
     int attn_dev_word = 0;                        // dev: probes of attention_tr_kernel (0 in the product path)
     unsigned long long* attn_stamps = nullptr;    // dev: per-block time stamps
@@ -213,7 +217,15 @@ extern "C" void arx_encoder_destroy(arx_encoder* h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->tap) (void)hipFree(h->tap);
     if (h->fold_ws) (void)hipFree(h->fold_ws);
+    if (h->small_ws) (void)hipFree(h->small_ws);
     delete h;
+}
+
+extern "C" int32_t arx_encoder_set_low_latency(arx_encoder* h, int32_t on) {
+    ARX_REQUIRE(h, "null handle");
+    if (on && !h->small_ws) ARX_HIP_CHECK(hipMalloc((void**)&h->small_ws, ARX_SMALL_WS_BYTES));
+    h->low_latency = on ? 1 : 0;
+    return ARX_OK;
 }
 
 extern "C" int32_t arx_encoder_set_tap(arx_encoder* h, int32_t layer) {
@@ -329,8 +341,9 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
 
 template <int MODE>
 static int launch_gemm(int cls, int variant, const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, int M, int N, int K,
-                       const EpiParams& ep, hipStream_t st) {
+                       const EpiParams& ep, hipStream_t st, float* small_ws = nullptr) {
     ProfScope ps(cls, st);
+    if (variant == 70) return launch_gemm_small<MODE>(A, lda, W, ldw, M, N, K, ep, small_ws, st);      // small-batch path (gemm_small.h)
 #ifdef ARX_DEV_VARIANTS
     static const int dev_bw = getenv("ARX_DEV_BW") ? atoi(getenv("ARX_DEV_BW")) : 0;      // dev A/B in situ: tile-walk band width
     if (dev_bw) { EpiParams e2 = ep; e2.dev_bw = dev_bw; return arx_launch_gemm<MODE>(variant, A, lda, W, ldw, M, N, K, e2, st); }
@@ -385,6 +398,22 @@ extern "C" int32_t arx_gemm_bf16(const void* A, const void* W, const float* bias
     }
 #endif
     ProfScope ps(ARX_K_GEMM_FC1, st);
+    if (variant == 70) {          // small-batch path alone (tests / tuning): one process-lifetime workspace per device for this entry point
+        static float* ws[64] = {nullptr};
+        static std::mutex mu;
+        int dev = 0;
+        ARX_HIP_CHECK(hipGetDevice(&dev));
+        ARX_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d", dev);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (!ws[dev]) ARX_HIP_CHECK(hipMalloc((void**)&ws[dev], ARX_SMALL_WS_BYTES));
+        }
+        switch (mode) {
+        case EPI_BIAS: return launch_gemm_small<EPI_BIAS>((const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, ws[dev], st);
+        case EPI_BIAS_GELU: return launch_gemm_small<EPI_BIAS_GELU>((const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, ws[dev], st);
+        case EPI_BIAS_RESID: return launch_gemm_small<EPI_BIAS_RESID>((const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, ws[dev], st);
+        }
+    }
     switch (mode) {
     case EPI_BIAS: return arx_launch_gemm<EPI_BIAS>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
     case EPI_BIAS_GELU: return arx_launch_gemm<EPI_BIAS_GELU>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
@@ -586,42 +615,45 @@ extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32
     //   x  : layer 0 -> embeddings (already normalised);  afterwards the PRE-LN2 sum y2 of the previous layer
     //   x1 : PRE-LN1 sum y1 of the current layer;  (st1, st2) : row sums / sums of squares of y1 / y2
     const float inv_h = 1.0f / (float)H;
+    const int gv = (h->low_latency && T <= ARX_SMALL_M) ? 70 : h->variant;      // a query batch: split-K wave tiles instead of 256 x 256 tiles
     if (h->tap_layer == 0 && h->tap) ARX_HIP_CHECK(hipMemcpyAsync(h->tap, h->x, (int64_t)T * H * 2, hipMemcpyDeviceToDevice, st));
     for (int li = 0; li < c.layers; ++li) {
         const arx_layer_weights& L = h->layers[li];
         EpiParams ep;
         if (li == 0) {
             ep = EpiParams{h->qkv, 3 * (int64_t)H, L.b_qkv, nullptr, 0};
-            if ((rc = launch_gemm<EPI_BIAS>(ARX_K_GEMM_QKV, h->variant, h->x, H, (const uint16_t*)L.w_qkv, H, T, 3 * H, H, ep, st)) != ARX_OK) return rc;
+            if ((rc = launch_gemm<EPI_BIAS>(ARX_K_GEMM_QKV, gv, h->x, H, (const uint16_t*)L.w_qkv, H, T, 3 * H, H, ep, st, h->small_ws)) != ARX_OK) return rc;
         } else {
             ep = EpiParams{h->qkv, 3 * (int64_t)H, h->c_qkv[li], nullptr, 0};
             ep.a_sum = h->st2_sum; ep.a_sq = h->st2_sq; ep.s_vec = h->s_qkv[li]; ep.inv_h = inv_h; ep.eps = c.ln_eps;
-            if ((rc = launch_gemm<EPI_LN_BIAS>(ARX_K_GEMM_QKV, h->variant, h->x, H, h->wqkv_f[li], H, T, 3 * H, H, ep, st)) != ARX_OK) return rc;
+            if ((rc = launch_gemm<EPI_LN_BIAS>(ARX_K_GEMM_QKV, gv, h->x, H, h->wqkv_f[li], H, T, 3 * H, H, ep, st, h->small_ws)) != ARX_OK) return rc;
         }
         if ((rc = launch_attn(h, n_seqs, max_len, st)) != ARX_OK) return rc;
         // y1 = ctx Wo^T + b + (x0 | LN2_prev(y2))  -> x1, statistics -> st1
         ep = EpiParams{h->x1, H, L.b_o, h->x, H};
         ep.o_sum = h->part_s; ep.o_sq = h->part_q; ep.o_ld = tp; ep.inv_h = inv_h; ep.eps = c.ln_eps;
+        ep.fin_mean = h->st1_sum; ep.fin_rstd = h->st1_sq;          // (small-batch path: statistics in final form, no ln_finalize)
         if (li == 0) {
-            if ((rc = launch_gemm<EPI_RESID_STATS>(ARX_K_GEMM_OPROJ, h->variant, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st)) != ARX_OK) return rc;
+            if ((rc = launch_gemm<EPI_RESID_STATS>(ARX_K_GEMM_OPROJ, gv, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st, h->small_ws)) != ARX_OK) return rc;
         } else {
             const arx_layer_weights& P = h->layers[li - 1];
             ep.r_sum = h->st2_sum; ep.r_sq = h->st2_sq; ep.r_gamma = P.ln2_g; ep.r_beta = P.ln2_b;
-            if ((rc = launch_gemm<EPI_LNRESID_STATS>(ARX_K_GEMM_OPROJ, h->variant, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st)) != ARX_OK) return rc;
+            if ((rc = launch_gemm<EPI_LNRESID_STATS>(ARX_K_GEMM_OPROJ, gv, h->ctx, H, (const uint16_t*)L.w_o, H, T, H, H, ep, st, h->small_ws)) != ARX_OK) return rc;
         }
-        { ProfScope ps(ARX_K_LAYERNORM, st);
+        if (gv != 70) { ProfScope ps(ARX_K_LAYERNORM, st);
           launch_ln_finalize(T, H / 64, h->part_s, h->part_q, tp, h->cu + n_seqs, inv_h, c.ln_eps, h->st1_sum, h->st1_sq, st); }
         ARX_HIP_CHECK(hipGetLastError());
         // hbuf = gelu(LN1(y1) W1^T + b1)   (gamma1 folded into W1')
         ep = EpiParams{h->hbuf, F, h->c_fc1[li], nullptr, 0};
         ep.a_sum = h->st1_sum; ep.a_sq = h->st1_sq; ep.s_vec = h->s_fc1[li]; ep.inv_h = inv_h; ep.eps = c.ln_eps;
-        if ((rc = launch_gemm<EPI_LN_BIAS_GELU>(ARX_K_GEMM_FC1, h->variant, h->x1, H, h->wfc1_f[li], H, T, F, H, ep, st)) != ARX_OK) return rc;
+        if ((rc = launch_gemm<EPI_LN_BIAS_GELU>(ARX_K_GEMM_FC1, gv, h->x1, H, h->wfc1_f[li], H, T, F, H, ep, st, h->small_ws)) != ARX_OK) return rc;
         // y2 = hbuf W2^T + b2 + LN1(y1)  -> x, statistics -> st2
         ep = EpiParams{h->x, H, L.b_fc2, h->x1, H};
         ep.r_sum = h->st1_sum; ep.r_sq = h->st1_sq; ep.r_gamma = L.ln1_g; ep.r_beta = L.ln1_b;
         ep.o_sum = h->part_s; ep.o_sq = h->part_q; ep.o_ld = tp; ep.inv_h = inv_h; ep.eps = c.ln_eps;
-        if ((rc = launch_gemm<EPI_LNRESID_STATS>(ARX_K_GEMM_FC2, h->variant, h->hbuf, F, (const uint16_t*)L.w_fc2, F, T, H, F, ep, st)) != ARX_OK) return rc;
-        { ProfScope ps(ARX_K_LAYERNORM, st);
+        ep.fin_mean = h->st2_sum; ep.fin_rstd = h->st2_sq;
+        if ((rc = launch_gemm<EPI_LNRESID_STATS>(ARX_K_GEMM_FC2, gv, h->hbuf, F, (const uint16_t*)L.w_fc2, F, T, H, F, ep, st, h->small_ws)) != ARX_OK) return rc;
+        if (gv != 70) { ProfScope ps(ARX_K_LAYERNORM, st);
           launch_ln_finalize(T, H / 64, h->part_s, h->part_q, tp, h->cu + n_seqs, inv_h, c.ln_eps, h->st2_sum, h->st2_sq, st); }
         ARX_HIP_CHECK(hipGetLastError());
         if (h->tap_layer == li + 1 && h->tap) {       // parity tap: materialise LN2(y2) with the stand-alone kernel

@@ -211,6 +211,8 @@ struct EpiParams {
     float* o_sq = nullptr;          // [N/64][o_ld] partial sums of squares
     int64_t o_ld = 0;
     float inv_h = 0.f, eps = 0.f;
+    float* fin_mean = nullptr;      // small-batch path only (gemm_small.h, modes 5/6): the output row's mean / rstd, written in final form
+    float* fin_rstd = nullptr;
 #ifdef ARX_DEV_VARIANTS
     int dev_store = 0;              // dev A/B: 0 plain stores, 1 non-temporal, 2 sc1 (write-through, line dropped from L2)
     int dev_bw = 0;                 // dev A/B: band width of the tile walk in n-tiles (0 = TileWalk's own choice)

@@ -101,6 +101,7 @@ class HipEncoder:
                                                C.byref(h)), "arx_encoder_create")
         self._handle = h
         self._cap = (max_tokens, max_seqs)
+        self._low_latency = False
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
@@ -118,12 +119,17 @@ class HipEncoder:
     # ---- forward --------------------------------------------------------------------------------
     def forward_tokens(self, ids: torch.Tensor, lens: torch.Tensor, max_len: int, total_tokens: int,
                        out: Optional[torch.Tensor] = None, out_f16: Optional[torch.Tensor] = None,
-                       normalize: bool = True) -> Optional[torch.Tensor]:
+                       normalize: bool = True, low_latency: bool = False) -> Optional[torch.Tensor]:
         """ids int32 [B, S] (device), lens int32 [B] (device) -> f32 [B, H] (device).  Launches on the
-        current torch stream; `out_f16` (fp16 [B, >=H], e.g. a slice of the corpus shard) is written in place."""
+        current torch stream; `out_f16` (fp16 [B, >=H], e.g. a slice of the corpus shard) is written in place.
+        `low_latency`: a forward of <= 256 token rows (a query batch) runs the split-K small-batch schedule
+        (`arx_encoder_set_low_latency`); rows then agree with the default schedule to rounding, not bit for bit."""
         B, S = ids.shape
         assert ids.dtype == torch.int32 and lens.dtype == torch.int32 and ids.is_contiguous() and lens.is_contiguous()
         self._ensure_capacity(total_tokens, B)
+        if bool(low_latency) != self._low_latency:
+            _lib.check(self.lib.arx_encoder_set_low_latency(self._handle, 1 if low_latency else 0), "arx_encoder_set_low_latency")
+            self._low_latency = bool(low_latency)
         if out is None and out_f16 is None:
             out = torch.empty((B, self.cfg.hidden), dtype=torch.float32, device=self.device)
         rc = self.lib.arx_encoder_forward(
@@ -134,7 +140,7 @@ class HipEncoder:
         _lib.check(rc, "arx_encoder_forward")
         return out
 
-    def encode_tokens(self, ids: np.ndarray, lens: np.ndarray, normalize: bool = True) -> torch.Tensor:
+    def encode_tokens(self, ids: np.ndarray, lens: np.ndarray, normalize: bool = True, low_latency: bool = False) -> torch.Tensor:
         """Right-padded ids [B, S] + lens [B] (host arrays) -> f32 [B, H] device tensor."""
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
@@ -144,7 +150,7 @@ class HipEncoder:
         total = max(int(lens.sum()), 1)
         d_ids = torch.from_numpy(ids).to(self.device, non_blocking=True)
         d_lens = torch.from_numpy(lens).to(self.device, non_blocking=True)
-        return self.forward_tokens(d_ids, d_lens, max_len, total, normalize=normalize)
+        return self.forward_tokens(d_ids, d_lens, max_len, total, normalize=normalize, low_latency=low_latency)
 
     @staticmethod
     def _pad_batch(seqs: Sequence[Sequence[int]], idx: Sequence[int], pad_id: int):
@@ -162,7 +168,7 @@ class HipEncoder:
         return ids, lens
 
     def encode_ragged(self, seqs: Sequence[Sequence[int]], batch_size: int = 256, normalize: bool = True,
-                      on_device: bool = False, out_f16: Optional[torch.Tensor] = None):
+                      on_device: bool = False, out_f16: Optional[torch.Tensor] = None, low_latency: bool = False):
         """Token-id lists -> f32 [n, H] numpy, input order preserved.  Sorted by length (descending, as
         sentence-transformers does) so each forward pads to a similar length; results do not depend on
         batch composition (key-padding mask), so the re-bucketing is invisible to the caller.  All forwards of the
@@ -183,7 +189,8 @@ class HipEncoder:
             d_ids = torch.from_numpy(ids).to(self.device, non_blocking=True)
             d_lens = torch.from_numpy(lens).to(self.device, non_blocking=True)
             self.forward_tokens(d_ids, d_lens, ids.shape[1], max(int(lens.sum()), 1), out=dev_out[s0:s0 + len(idx)],
-                                out_f16=None if dev16 is None else dev16[s0:s0 + len(idx)], normalize=normalize)
+                                out_f16=None if dev16 is None else dev16[s0:s0 + len(idx)], normalize=normalize,
+                                low_latency=low_latency)
         order_t = torch.as_tensor(order, device=self.device) if (on_device or dev16 is not None) else None
         if dev16 is not None:
             out_f16[:, :self.cfg.hidden].index_copy_(0, order_t, dev16)
@@ -204,7 +211,7 @@ class HipEncoder:
         return torch.empty((n, self.cfg.hidden), dtype=torch.float16, device=self.device)
 
     def encode_packed(self, ids: np.ndarray, lens: np.ndarray, batch_size: int = 256, normalize: bool = True,
-                      on_device: bool = False, out_f16: Optional[torch.Tensor] = None):
+                      on_device: bool = False, out_f16: Optional[torch.Tensor] = None, low_latency: bool = False):
         """`encode_ragged` for a tokenizer that already produced a right-padded id matrix (int32 [n, W]) and lengths: no
         per-token Python objects anywhere on the host path.  Same length-sorted batching, same rows."""
         n = int(len(lens))
@@ -222,7 +229,8 @@ class HipEncoder:
             d_ids = torch.from_numpy(np.ascontiguousarray(ids[idx, :ml], dtype=np.int32)).to(self.device, non_blocking=True)
             d_lens = torch.from_numpy(np.ascontiguousarray(bl)).to(self.device, non_blocking=True)
             self.forward_tokens(d_ids, d_lens, ml, max(int(bl.sum()), 1), out=dev_out[s0:s0 + len(idx)],
-                                out_f16=None if dev16 is None else dev16[s0:s0 + len(idx)], normalize=normalize)
+                                out_f16=None if dev16 is None else dev16[s0:s0 + len(idx)], normalize=normalize,
+                                low_latency=low_latency)
         order_t = torch.from_numpy(order).to(self.device) if (on_device or dev16 is not None) else None
         if dev16 is not None:
             out_f16[:, :self.cfg.hidden].index_copy_(0, order_t, dev16)
@@ -292,11 +300,12 @@ class HipSentenceEncoder:
             return ("packed", ids, lens)
         return ("ragged", self.tokenize(sentences))
 
-    def _encode_tokens_any(self, toks, bs: int, normalize: bool, on_device: bool = False, out_f16=None):
+    def _encode_tokens_any(self, toks, bs: int, normalize: bool, on_device: bool = False, out_f16=None, low_latency: bool = False):
         if toks[0] == "packed":
             return self.encoder.encode_packed(toks[1], toks[2], batch_size=bs, normalize=normalize, on_device=on_device,
-                                              out_f16=out_f16)
-        return self.encoder.encode_ragged(toks[1], batch_size=bs, normalize=normalize, on_device=on_device, out_f16=out_f16)
+                                              out_f16=out_f16, low_latency=low_latency)
+        return self.encoder.encode_ragged(toks[1], batch_size=bs, normalize=normalize, on_device=on_device, out_f16=out_f16,
+                                          low_latency=low_latency)
 
     def encode_device(self, sentences: Sequence[str], batch_size: int = 32, normalize_embeddings: bool = False) -> torch.Tensor:
         """Rows stay in HBM (f32 [n, D], input order) — for GPU-side consumers (adjacent cosine, the search index)."""
@@ -305,9 +314,11 @@ class HipSentenceEncoder:
 
     def encode(self, sentences, batch_size: int = 32, show_progress_bar=None, convert_to_numpy: bool = True,
                convert_to_tensor: bool = False, normalize_embeddings: bool = False, device_f16_out: Optional[torch.Tensor] = None,
-               **_ignored):
+               low_latency: bool = False, **_ignored):
         """`device_f16_out` (additive; device fp16 [n, >= D]): the same rows, as the kernel's own fp16 output, are also left in
-        HBM in input order — the CLI passes a slice of the rank's corpus shard, so the search step never re-uploads them."""
+        HBM in input order — the CLI passes a slice of the rank's corpus shard, so the search step never re-uploads them.
+        `low_latency` (additive): for QUERY texts — a forward of <= 256 token rows takes the small-batch schedule
+        (`arx_encoder_set_low_latency`: 1.5 -> 0.56 ms for one query at the mpnet-base shape); rows agree with the default to rounding."""
         single = isinstance(sentences, str)
         if single:
             sentences = [sentences]
@@ -316,7 +327,8 @@ class HipSentenceEncoder:
         slab = max(bs, self.slab_texts)
         first = max(bs, self.first_slab_texts)
         if len(sentences) <= first:
-            emb = self._encode_tokens_any(self._tokenize_any(sentences), bs, normalize_embeddings, out_f16=device_f16_out)
+            emb = self._encode_tokens_any(self._tokenize_any(sentences), bs, normalize_embeddings, out_f16=device_f16_out,
+                                          low_latency=low_latency)
         else:
             # feeder: the tokenizer (native C++ or Rust; both release the GIL) works on slab i+1 in a helper thread while the GPU encodes slab i;
             # slabs grow 1024, 2048, ... up to slab_texts so the GPU starts after ~25 ms of tokenisation, not a whole slab

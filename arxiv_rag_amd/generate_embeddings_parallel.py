@@ -478,7 +478,7 @@ def search_queries(model, chunks: List[Dict], shard: "ShardSink", queries: List[
     rank = dist.get_rank() if dist else 0
     dev = model.encoder.device
     qd = torch.empty((len(queries), model.get_sentence_embedding_dimension()), dtype=torch.float16, device=dev)
-    model.encode(queries, batch_size=256, normalize_embeddings=True, convert_to_numpy=True, device_f16_out=qd)
+    model.encode(queries, batch_size=256, normalize_embeddings=True, convert_to_numpy=True, device_f16_out=qd, low_latency=True)
     s, i = ShardIndex(shard.rows, idx_base=shard.lo).search_distributed(qd, top_k)
     s, i = s.cpu().numpy(), i.cpu().numpy()
     results = []

@@ -71,7 +71,7 @@ class HipCollection:
         if query_embeddings is None:
             if query_texts is None or self.encoder is None:
                 raise ValueError("pass query_embeddings, or query_texts with an encoder")
-            query_embeddings = self.encoder.encode(list(query_texts), normalize_embeddings=True, convert_to_numpy=True)
+            query_embeddings = self.encoder.encode(list(query_texts), normalize_embeddings=True, convert_to_numpy=True, low_latency=True)
         q = torch.from_numpy(np.ascontiguousarray(query_embeddings, dtype=np.float16)).to(self.index.corpus.device)
         if q.dim() == 1:
             q = q[None]

@@ -121,6 +121,15 @@ int32_t arx_encoder_attention(arx_encoder* h, const void* qkv, const int32_t* le
 /* Debug / parity tap: copy the packed hidden state after `layer` (0 = embeddings, L = last) as f32
  * [total_tokens, H] into dst (device).  Valid after a forward on the same stream. */
 int32_t arx_encoder_debug_hidden(arx_encoder* h, int32_t layer_slot, float* dst, int32_t n_tokens, void* stream);
+
+/* Opt-in small-batch schedule for QUERY batches (no reference counterpart: the reference encodes its queries with the same
+ * `model.encode` as the corpus, GEN:146-153).  With on != 0, a forward of at most 256 packed token rows runs its linear layers as
+ * split-K wave tiles (csrc/gemm_small.h: every CU takes part and each weight byte is read once) instead of 256 x 256 tiles that
+ * leave all but a few CUs idle; longer forwards are unaffected.  Rows agree with the default schedule to rounding (another
+ * summation order), not bit for bit: leave it off for corpus rows if their bits must not depend on the batch they were in.
+ * Allocates the handle's 64-MiB partial-sum workspace on first use (freed by arx_encoder_destroy). */
+int32_t arx_encoder_set_low_latency(arx_encoder* h, int32_t on);
+
 /* Ask the next forward() to snapshot the hidden state after `layer` (-1 = off). */
 int32_t arx_encoder_set_tap(arx_encoder* h, int32_t layer);
 

@@ -97,7 +97,7 @@ def test_cli_drop_in_end_to_end_on_gpu(hip, tmp_path, monkeypatch, tokenizer_jso
     # exact statement of the same step: top-10 over the fp16 rows the kernels wrote, queries as the kernels encoded them
     model = GEN._model
     qd = torch.empty((len(qs), 384), dtype=torch.float16, device="cuda")
-    model.encode(qs, normalize_embeddings=True, device_f16_out=qd)
+    model.encode(qs, normalize_embeddings=True, device_f16_out=qd, low_latency=True)   # as search_queries encodes them
     rs2, ri2 = SO.topk_search(arr.astype(np.float16), qd.cpu().numpy(), 11)
     for qi, r in enumerate(res):
         got = [h["index"] for h in r["results"]]
@@ -200,7 +200,7 @@ def test_sharded_branch_single_rank_nccl(nccl_world1, tmp_path, monkeypatch):
     assert [m["chunk_id"] for m in meta] == [c["chunk_id"] for c in chunks]
     r_dev = GEN.search_queries(model, chunks, sink, qs, top_k=10, output_dir=str(tmp_path / "embeddings_saved"))
     qd = torch.empty((len(qs), 384), dtype=torch.float16, device="cuda")
-    model.encode(qs, normalize_embeddings=True, device_f16_out=qd)
+    model.encode(qs, normalize_embeddings=True, device_f16_out=qd, low_latency=True)   # as search_queries encodes them
     # results unchanged by where the shard came from: the same search over the rows of the .npy file, uploaded here by the test
     from arxiv_rag_amd.index import ShardIndex
     s_up, i_up = ShardIndex(torch.from_numpy(arr.astype(np.float16)).cuda(), idx_base=lo).search_distributed(qd, 10)

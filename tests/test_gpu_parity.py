@@ -689,6 +689,77 @@ def test_alternative_schedules_agree(hip, golden_dir, env, monkeypatch):
     assert _cos(e1, e0).min() > 1 - 3e-4
 
 
+def test_small_batch_gemm_vs_fp32_and_tile_kernels(hip):
+    """csrc/gemm_small.h alone (arx_gemm_bf16 variant 70): split-K wave tiles + row-wise epilogue, at every (N, K) the encoders use,
+    at row counts around its 16-row tile (1, 12, 16, 17, 100, 256), modes bias / bias+GELU / bias+residual, against fp32 torch on the
+    same bf16 operands and against the 256 x 256-tile kernels (one bf16 ulp: another summation order)."""
+    lib = hip.load()
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    st = torch.cuda.current_stream().cuda_stream
+    for (N, K) in ((2304, 768), (768, 768), (3072, 768), (768, 3072), (1152, 384), (384, 384), (1536, 384), (384, 1536),
+                   (3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096), (192, 64), (128, 64), (64, 128)):
+        W = (torch.randn((N, K), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn((N,), device="cuda", generator=g)
+        for M in (1, 12, 16, 17, 100, 256):
+            A = torch.randn((M, K), device="cuda", generator=g).to(torch.bfloat16)
+            R = torch.randn((M, N), device="cuda", generator=g).to(torch.bfloat16)
+            for mode in (0, 1, 2):
+                outs = []
+                for variant in (70, 13):
+                    out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+                    hip.check(lib.arx_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, mode,
+                                                variant, st), "arx_gemm_bf16")
+                    outs.append(out.float())
+                want = A.float() @ W.float().T + b
+                want = torch.nn.functional.gelu(want) if mode == 1 else want + R.float() if mode == 2 else want
+                tol = 0.01 * max(1.0, want.abs().max().item())
+                assert (outs[0] - want).abs().max().item() < tol, (N, K, M, mode)
+                assert (outs[0] - outs[1]).abs().max().item() < tol, (N, K, M, mode)
+    # a second call on the same inputs: bit-repeatable (fixed split order)
+    out2 = torch.empty_like(out)
+    hip.check(lib.arx_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), out2.data_ptr(), M, N, K, mode, 70, st), "arx_gemm_bf16")
+    hip.check(lib.arx_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, mode, 70, st), "arx_gemm_bf16")
+    assert torch.equal(out.view(torch.int16), out2.view(torch.int16))
+    with pytest.raises(hip.ArxError):          # beyond its row limit the small-batch path refuses (the forward never sends such a batch there)
+        big = torch.zeros((300, K), device="cuda", dtype=torch.bfloat16)
+        o = torch.empty((300, N), device="cuda", dtype=torch.bfloat16)
+        hip.check(lib.arx_gemm_bf16(big.data_ptr(), W.data_ptr(), b.data_ptr(), o.data_ptr(), o.data_ptr(), 300, N, K, 0, 70, st), "arx_gemm_bf16")
+
+
+@pytest.mark.parametrize("key,cfg", [("all-mpnet-base-v2:w05", C.MPNET_BASE), ("all-MiniLM-L6-v2:w05", C.MINILM_L6),
+                                     ("BAAI_bge-large-en-v1.5:w05", C.BGE_LARGE)])
+def test_low_latency_schedule_on_query_batches(hip, golden_dir, key, cfg):
+    """`arx_encoder_set_low_latency`: query-sized batches (1, 3, 8 short sequences: <= 256 token rows) through the split-K schedule,
+    against the golden vectors (transformers fp32 modules) of the same sequences and against the default schedule of the same handle; a batch above 256 rows with the option ON takes the default kernels and is bit-identical to the option OFF."""
+    from arxiv_rag_amd.encoder import HipEncoder
+    g = np.load(golden_dir / "full_shapes.npz")
+    if key + ":ids" not in g.files:
+        pytest.skip(f"{key} not in the fixture")
+    seed, std, bstd, jit = g[key + ":wspec"]
+    sd = seeded_state_dict(cfg, seed=int(seed), std=std, bias_std=bstd, ln_jitter=jit)
+    ids, lens, ref = g[key + ":ids"], g[key + ":lens"], g[key + ":emb"]
+    enc = HipEncoder(cfg, sd)
+    order = np.argsort(lens)                       # the fixture's shortest sequences first
+    for take in (1, 3, 8):
+        idx = order[:take]
+        while int(lens[idx].sum()) > 256 and len(idx) > 1:
+            idx = idx[:-1]
+        if int(lens[idx].sum()) > 256:
+            continue
+        sub_ids = ids[idx][:, :int(lens[idx].max())]
+        e_def = enc.encode_tokens(sub_ids, lens[idx]).cpu().numpy()
+        e_ll = enc.encode_tokens(sub_ids, lens[idx], low_latency=True).cpu().numpy()
+        assert np.isfinite(e_ll).all()
+        assert _cos(e_ll, ref[idx]).min() > 1 - 1e-3            # rows do not depend on the batch they are in: the fixture's rows apply
+        assert _cos(e_ll, e_def).min() > 1 - 3e-4
+        assert not np.array_equal(e_ll, e_def) or take == 0      # it IS another schedule (else this test tests nothing)
+    big = enc.encode_tokens(ids, lens).cpu().numpy()
+    big_ll = enc.encode_tokens(ids, lens, low_latency=True).cpu().numpy()
+    if int(lens.sum()) > 256:
+        assert np.array_equal(big, big_ll)
+    enc.close()
+
+
 @pytest.mark.parametrize("name,lens", [("all-MiniLM-L6-v2", [512, 400, 300, 257, 511, 33]),
                                        ("all-mpnet-base-v2", [384, 300, 257, 383, 5])])
 def test_long_sequences_vs_oracle(hip, name, lens):
