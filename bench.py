@@ -272,7 +272,20 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        # RCCL printf()s a five-line version banner to STDOUT when the communicator is created (NCCL_DEBUG_FILE does not move it); stdout
+        # carries the one JSON line of the contract, so file descriptor 1 points at stderr while the group comes up
+        sys.stdout.flush()
+        fd1 = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            torch.cuda.set_device(local_rank)
+            dist.barrier()                               # the communicator exists (and has said so) before stdout comes back
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(fd1, 1)
+            os.close(fd1)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
@@ -413,9 +426,32 @@ def main():
                                "passA_hbm_frac": round(passes_bytes / (gms / gn * 1e-3) / HBM_PEAK, 4),
                                "passA_tflops": round(2 * min(qb, 1024) * N * D / (gms / gn * 1e-3) / 1e12, 1),
                                "select_ms": round(p["search_select"][0] / reps, 3), "rescore_ms": round(p["search_rescore"][0] / reps, 3)}
+        # the same step from query TEXT lengths (16 synthetic token ids per query): encode on the small-batch schedule
+        # (arx_encoder_set_low_latency, <= 256 token rows) into an fp16 device matrix, then the search above
+        from_tokens = {}
+        rs_q = np.random.RandomState(99)
+        for qb in (1, 16):
+            qids = rs_q.randint(4, cfg.vocab_size - 1, size=(qb, 16)).astype(np.int32); qids[:, 0] = 0; qids[:, -1] = 2
+            d_q = torch.from_numpy(qids).to(dev); d_l = torch.full((qb,), 16, dtype=torch.int32, device=dev)
+            q16 = torch.empty((qb, D), dtype=torch.float16, device=dev)
+            lat = {}
+            for tag, ll in (("default_schedule", False), ("small_batch_schedule", True)):
+                def one():
+                    enc.forward_tokens(d_q, d_l, 16, qb * 16, out=None, out_f16=q16, normalize=True, low_latency=ll)
+                    return idx.search_distributed(q16, 10)
+                for _ in range(3): one()
+                torch.cuda.synchronize(dev)
+                ts = []
+                for _ in range(15):
+                    t0 = time.perf_counter(); one(); torch.cuda.synchronize(dev); ts.append(time.perf_counter() - t0)
+                lat[tag + "_ms"] = round(float(np.median(ts)) * 1e3, 3)
+            lat["qps_small_batch"] = round(qb / (lat["small_batch_schedule_ms"] * 1e-3), 1)
+            from_tokens[f"Qb={qb}"] = lat
         r64 = res.get("Qb=64") or next(iter(res.values()))
         straffic = tjson.get("search_groupmax64_hbm_bytes_per_launch")
         search = {"workload": f"{N} x {D} fp16 rows per rank, {nq_all} queries, k=10, world {world}", "results": res,
+                  "encode_plus_search": {"note": "queries given as 16 token ids each: encoder forward + top-10 search, GPU-synchronised wall time per batch",
+                                         **from_tokens},
                   "roofline": {"kernel": "search_groupmax_kernel<64> (pass A at Qb=64)", "bound": "hbm",
                                "achieved": r64["passA_hbm_GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                "frac": r64["passA_hbm_frac"], "traffic": straffic if N == 10_000_000 and D == 768 else None,

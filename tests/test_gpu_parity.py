@@ -760,6 +760,28 @@ def test_low_latency_schedule_on_query_batches(hip, golden_dir, key, cfg):
     enc.close()
 
 
+@pytest.mark.parametrize("cfg", [C.TINY_MPNET, C.TINY_BERT], ids=["tiny-mpnet", "tiny-bert"])
+def test_low_latency_schedule_tiny_configs_vs_oracle(hip, cfg):
+    """the small-batch schedule at the smallest shapes (H = 64: one 64-column tile per row, K = 64: two k-steps) on a ragged batch incl.
+    1-token and full-length sequences, against the fp32 oracle and the default schedule"""
+    from arxiv_rag_amd.encoder import HipEncoder
+    sd = seeded_state_dict(cfg, seed=2, std=0.05, bias_std=0.05, ln_jitter=0.1)
+    rs = np.random.RandomState(1)
+    lens = np.array([64, 40, 17, 5, 1, 33, 64, 2], np.int64)           # 226 token rows
+    ids = np.full((len(lens), 64), cfg.pad_id, np.int64)
+    for r, n in enumerate(lens):
+        ids[r, :n] = rs.randint(4, cfg.vocab_size, size=n)
+    ref = EO.encode_tokens(sd, cfg, ids, lens)
+    enc = HipEncoder(cfg, sd)
+    e_def = enc.encode_tokens(ids, lens).cpu().numpy()
+    e_ll = enc.encode_tokens(ids, lens, low_latency=True).cpu().numpy()
+    assert _cos(e_ll, ref).min() > 1 - 1e-3
+    assert _cos(e_ll, e_def).min() > 1 - 3e-4
+    e_ll2 = enc.encode_tokens(ids, lens, low_latency=True).cpu().numpy()
+    assert np.array_equal(e_ll, e_ll2)                                   # fixed split order: repeatable bit for bit
+    enc.close()
+
+
 @pytest.mark.parametrize("name,lens", [("all-MiniLM-L6-v2", [512, 400, 300, 257, 511, 33]),
                                        ("all-mpnet-base-v2", [384, 300, 257, 383, 5])])
 def test_long_sequences_vs_oracle(hip, name, lens):
