@@ -286,6 +286,11 @@ int arx_launch_gemm(int variant, const uint16_t* A, int64_t lda, const uint16_t*
         }
     }
 #endif
+    // 71: the 2-stage loop on 128 x 128 tiles (4 waves, two blocks per CU) — the medium-batch half of the opt-in low-latency schedule:
+    // between 256 and 8192 token rows a 256 x 256 grid leaves most CUs idle while each tile walks its whole K (17 us at K = 768, 70 us at
+    // K = 3072 whatever the row count); four times the tiles, a quarter of the work each
+    if (variant == 71)
+        return launch_gemm_kernel(gemm_v0e2_kernel<128, 128, 2, 2, MODE, 67>, GemmMainloop<bf16_t, 128, 128, 2, 2, true, 67>::SMEM_BYTES, 256, 128, 128, A, lda, W, ldw, M, N, K, ep, st);
     // 89 = DEFAULT: persistent kernel for the short-K shapes (K <= 1024: QKV, O-projection, FFN-1 — the per-tile first-load latency is
     // 10-14 % of such a tile; +2..4 % measured in situ, same box), per-tile kernel for the long-K one (FFN-2: -3 % when persistent)
     if (variant == 89) variant = (K <= 1024) ? 9 : 8;
@@ -615,7 +620,8 @@ extern "C" int32_t arx_encoder_forward(arx_encoder* h, const int32_t* ids, int32
     //   x  : layer 0 -> embeddings (already normalised);  afterwards the PRE-LN2 sum y2 of the previous layer
     //   x1 : PRE-LN1 sum y1 of the current layer;  (st1, st2) : row sums / sums of squares of y1 / y2
     const float inv_h = 1.0f / (float)H;
-    const int gv = (h->low_latency && T <= ARX_SMALL_M) ? 70 : h->variant;      // a query batch: split-K wave tiles instead of 256 x 256 tiles
+    // opt-in low-latency schedule: a query batch takes split-K wave tiles (<= 256 rows) or 128 x 128 tiles (<= 8192 rows) instead of 256 x 256 tiles
+    const int gv = !h->low_latency ? h->variant : (T <= ARX_SMALL_M ? 70 : (T <= ARX_MEDIUM_M ? 71 : h->variant));
     if (h->tap_layer == 0 && h->tap) ARX_HIP_CHECK(hipMemcpyAsync(h->tap, h->x, (int64_t)T * H * 2, hipMemcpyDeviceToDevice, st));
     for (int li = 0; li < c.layers; ++li) {
         const arx_layer_weights& L = h->layers[li];

@@ -13,6 +13,7 @@
 #include "gemm.h"
 
 #define ARX_SMALL_M 256            // packed token rows (16 m-tiles at most)
+#define ARX_MEDIUM_M 8192          // up to here the low-latency schedule uses 128 x 128 tiles (encoder.hip, variant 71)
 #define ARX_SMALL_WS_BYTES (64ll << 20)
 
 // partial products: ws[(split * Mp + m) * N + n] fp32, Mp = M rounded up to 16

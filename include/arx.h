@@ -125,7 +125,7 @@ int32_t arx_encoder_debug_hidden(arx_encoder* h, int32_t layer_slot, float* dst,
 /* Opt-in small-batch schedule for QUERY batches (no reference counterpart: the reference encodes its queries with the same
  * `model.encode` as the corpus, GEN:146-153).  With on != 0, a forward of at most 256 packed token rows runs its linear layers as
  * split-K wave tiles (csrc/gemm_small.h: every CU takes part and each weight byte is read once) instead of 256 x 256 tiles that
- * leave all but a few CUs idle; longer forwards are unaffected.  Rows agree with the default schedule to rounding (another
+ * leave all but a few CUs idle; forwards of up to 8 192 rows take 128 x 128 tiles; longer forwards are unaffected.  Rows agree with the default schedule to rounding (another
  * summation order), not bit for bit: leave it off for corpus rows if their bits must not depend on the batch they were in.
  * Allocates the handle's 64-MiB partial-sum workspace on first use (freed by arx_encoder_destroy). */
 int32_t arx_encoder_set_low_latency(arx_encoder* h, int32_t on);

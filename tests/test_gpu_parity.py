@@ -715,6 +715,23 @@ def test_small_batch_gemm_vs_fp32_and_tile_kernels(hip):
                 tol = 0.01 * max(1.0, want.abs().max().item())
                 assert (outs[0] - want).abs().max().item() < tol, (N, K, M, mode)
                 assert (outs[0] - outs[1]).abs().max().item() < tol, (N, K, M, mode)
+    # the medium half of the low-latency schedule (variant 71: 128 x 128 tiles) at row counts between its bounds, ragged edges included
+    for (N, K) in ((2304, 768), (768, 3072), (1152, 384), (1024, 4096), (192, 64)):
+        W = (torch.randn((N, K), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn((N,), device="cuda", generator=g)
+        for M in (257, 1000, 4097):
+            A = torch.randn((M, K), device="cuda", generator=g).to(torch.bfloat16)
+            R = torch.randn((M, N), device="cuda", generator=g).to(torch.bfloat16)
+            for mode in (0, 1, 2):
+                out = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+                hip.check(lib.arx_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), out.data_ptr(), M, N, K, mode, 71, st), "arx_gemm_bf16")
+                want = A.float() @ W.float().T + b
+                want = torch.nn.functional.gelu(want) if mode == 1 else want + R.float() if mode == 2 else want
+                assert (out.float() - want).abs().max().item() < 0.01 * max(1.0, want.abs().max().item()), (N, K, M, mode)
+    N, K, M, mode = 384, 1536, 256, 2
+    W = (torch.randn((N, K), device="cuda", generator=g) * 0.05).to(torch.bfloat16); b = torch.randn((N,), device="cuda", generator=g)
+    A = torch.randn((M, K), device="cuda", generator=g).to(torch.bfloat16); R = torch.randn((M, N), device="cuda", generator=g).to(torch.bfloat16)
+    out = torch.empty((M, N), device="cuda", dtype=torch.bfloat16)
     # a second call on the same inputs: bit-repeatable (fixed split order)
     out2 = torch.empty_like(out)
     hip.check(lib.arx_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), out2.data_ptr(), M, N, K, mode, 70, st), "arx_gemm_bf16")
@@ -753,10 +770,17 @@ def test_low_latency_schedule_on_query_batches(hip, golden_dir, key, cfg):
         assert _cos(e_ll, ref[idx]).min() > 1 - 1e-3            # rows do not depend on the batch they are in: the fixture's rows apply
         assert _cos(e_ll, e_def).min() > 1 - 3e-4
         assert not np.array_equal(e_ll, e_def) or take == 0      # it IS another schedule (else this test tests nothing)
+    # the whole fixture (up to ~1 800 token rows): the medium half of the option, 128 x 128 tiles
     big = enc.encode_tokens(ids, lens).cpu().numpy()
     big_ll = enc.encode_tokens(ids, lens, low_latency=True).cpu().numpy()
-    if int(lens.sum()) > 256:
-        assert np.array_equal(big, big_ll)
+    assert _cos(big_ll, ref).min() > 1 - 1e-3 and _cos(big_ll, big).min() > 1 - 3e-4
+    # above 8 192 rows the option changes nothing: bit-identical rows
+    reps = 8192 // max(int(lens.sum()), 1) + 1
+    ids_r, lens_r = np.tile(ids, (reps, 1)), np.tile(lens, reps)
+    assert int(lens_r.sum()) > 8192
+    huge = enc.encode_tokens(ids_r, lens_r).cpu().numpy()
+    huge_ll = enc.encode_tokens(ids_r, lens_r, low_latency=True).cpu().numpy()
+    assert np.array_equal(huge, huge_ll)
     enc.close()
 
 

@@ -39,7 +39,7 @@ def captured(fn):
     return g
 
 
-for (nq, L) in ((1, 12), (4, 16), (16, 16), (16, 24), (64, 32)):
+for (nq, L) in ((1, 12), (4, 16), (16, 16), (16, 24), (64, 16), (64, 32), (256, 32), (512, 32)):
     ids = rs.randint(4, cfg.vocab_size - 1, size=(nq, L)).astype(np.int32); ids[:, 0] = 0; ids[:, -1] = 2
     lens = np.full(nq, L, np.int32)
     d_ids = torch.from_numpy(ids).cuda(); d_lens = torch.from_numpy(lens).cuda()
@@ -58,6 +58,6 @@ for (nq, L) in ((1, 12), (4, 16), (16, 16), (16, 24), (64, 32)):
             res["cos_min_vs_default"] = float(torch.nn.functional.cosine_similarity(o, ref_default, dim=1).min())
         else:
             ref_default = ref
-    res["takes_small_batch_path"] = nq * L <= 256
+    res["schedule"] = "split-K wave tiles" if nq * L <= 256 else ("128 x 128 tiles" if nq * L <= 8192 else "default")
     out[f"nq={nq},L={L}"] = res
 print(json.dumps(out))
