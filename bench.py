@@ -250,6 +250,9 @@ def main():
     ap.add_argument("--search-rows", type=int, default=10_000_000, help="corpus rows per rank (0 = skip search leg)")
     ap.add_argument("--search-queries", type=int, default=10_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-query-leg", action="store_true",
+                    help="skip search.encode_plus_search (its query-sized forwards launch the GEMM kernels on tiny problems: under rocprofv3 "
+                         "they would pollute the per-kernel averages the roofline figures are checked against)")
     ap.add_argument("--sustained-chunks", type=int, default=1_000_000,
                     help="untimed-by-driver leg: encode this many chunks back to back (configs[1] = 1 M; 0 = skip)")
     ap.add_argument("--prof-all-in-timed-region", action="store_true",
@@ -430,7 +433,7 @@ def main():
         # (arx_encoder_set_low_latency, <= 256 token rows) into an fp16 device matrix, then the search above
         from_tokens = {}
         rs_q = np.random.RandomState(99)
-        for qb in (1, 16):
+        for qb in (() if args.no_query_leg else (1, 16)):
             qids = rs_q.randint(4, cfg.vocab_size - 1, size=(qb, 16)).astype(np.int32); qids[:, 0] = 0; qids[:, -1] = 2
             d_q = torch.from_numpy(qids).to(dev); d_l = torch.full((qb,), 16, dtype=torch.int32, device=dev)
             q16 = torch.empty((qb, D), dtype=torch.float16, device=dev)
