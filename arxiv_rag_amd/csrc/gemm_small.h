@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void gemm_small_epilogue_kernel(const float* _
     if constexpr (LN_IN) { a_mean = p.a_sum[m]; a_rstd = p.a_sq[m]; }
     if constexpr (MODE == EPI_LNRESID_STATS) { r_mean = p.r_sum[m]; r_rstd = p.r_sq[m]; }
     float st_a = 0.f, st_q = 0.f;
-    for (int n = threadIdx.x * 4; n < N; n += 1024) {
+    // blockIdx.y: 1024-column slice of the row (modes without statistics are launched with one block per slice: the wide layers' rows —
+    // N = 2304, 3072, 4096 — no longer walk their slices one after the other); statistics modes have N <= 1024 = one slice
+    for (int n = blockIdx.y * 1024 + threadIdx.x * 4; n < N; n += 1024 * gridDim.y) {
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* src = ws + (int64_t)m * N + n;
         const int64_t sstride = (int64_t)Mp * N;
@@ -171,7 +173,12 @@ static int launch_gemm_small(const uint16_t* A, int64_t lda, const uint16_t* W, 
     if (ksteps <= 4) gemm_small_partial_kernel<4><<<grid, 64, 0, st>>>(A, lda, W, ldw, M, N, ksteps, ws);
     else gemm_small_partial_kernel<8><<<grid, 64, 0, st>>>(A, lda, W, ldw, M, N, ksteps, ws);
     ARX_HIP_CHECK(hipGetLastError());
-    gemm_small_epilogue_kernel<MODE><<<M, 256, 0, st>>>(ws, S, mt * 16, M, N, ep);
+    constexpr bool STATS = (MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS);
+    if (STATS && N > 1024) {
+        arx_set_error("small-batch gemm: statistics modes take N <= 1024 (the row is reduced inside one block), N=%d", N);
+        return ARX_ERR_ARG;
+    }
+    gemm_small_epilogue_kernel<MODE><<<dim3(M, STATS ? 1 : cdiv(N, 1024)), 256, 0, st>>>(ws, S, mt * 16, M, N, ep);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }

@@ -318,7 +318,7 @@ class HipSentenceEncoder:
         """`device_f16_out` (additive; device fp16 [n, >= D]): the same rows, as the kernel's own fp16 output, are also left in
         HBM in input order — the CLI passes a slice of the rank's corpus shard, so the search step never re-uploads them.
         `low_latency` (additive): for QUERY texts — a forward of <= 256 token rows takes the small-batch schedule
-        (`arx_encoder_set_low_latency`: 1.5 -> 0.56 ms for one query at the mpnet-base shape); rows agree with the default to rounding."""
+        (`arx_encoder_set_low_latency`: 1.5 -> 0.49 ms for one query at the mpnet-base shape); rows agree with the default to rounding."""
         single = isinstance(sentences, str)
         if single:
             sentences = [sentences]
