@@ -99,27 +99,33 @@ struct Gemm8Phase {
             for (int h = 0; h < 2; ++h) {
                 int gm = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
                 gm = gm < M ? gm : M - 1;
-                aoff[h][it] = (uint32_t)gm * (uint32_t)lda + c * 8;
+                aoff[h][it] = ((uint32_t)gm * (uint32_t)lda + c * 8) * 2u;      // BYTE offsets: the voffset operand of buffer_load ... lds
                 int gn = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
                 gn = gn < N ? gn : N - 1;
-                boff[h][it] = (uint32_t)gn * (uint32_t)ldw + c * 8;
+                boff[h][it] = ((uint32_t)gn * (uint32_t)ldw + c * 8) * 2u;
             }
         }
         const int nk = K >> 6;
         koff = koff % nk;
         auto kcol = [&](int kt) { int k = kt + koff; return (k >= nk ? k - nk : k) << 6; };
         char* const wave_dst = smem + wid * 1024;               // wave-uniform; lane l lands at +16*l
+        // LDS-DMA through BUFFER loads (buffer_load_dwordx4 v, s[rsrc], s_off offen lds): the per-lane part of the address is one
+        // loop-invariant 32-bit VGPR and the k-tile's column is the scalar offset — no 64-bit per-lane address arithmetic per piece,
+        // half the address registers through the texture addresser (the global_load_lds form cost 60-100 issue cycles per piece, and
+        // the load sections of phases 1 and 3 are what the k-loop waits for: profiles/r02/gemm_kloop_bisect.txt)
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, 0xffffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0xffffffff, 0x00020000);
         auto issue_a = [&](int h, int kt, int buf) {
-            const uint16_t* base = Ag + kcol(kt);
+            const int kb = kcol(kt) * 2;
             char* dst = wave_dst + buf * BUF_BYTES + h * HALF_BYTES;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + aoff[h][0]), (lds_void_t*)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + aoff[h][1]), (lds_void_t*)(dst + 8192), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)dst, 16, aoff[h][0], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(dst + 8192), 16, aoff[h][1], kb, 0, 0);
         };
         auto issue_b = [&](int g, int kt, int buf) {
-            const uint16_t* base = Wg + kcol(kt);
+            const int kb = kcol(kt) * 2;
             char* dst = wave_dst + buf * BUF_BYTES + (2 + g) * HALF_BYTES;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + boff[g][0]), (lds_void_t*)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + boff[g][1]), (lds_void_t*)(dst + 8192), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t*)dst, 16, boff[g][0], kb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t*)(dst + 8192), 16, boff[g][1], kb, 0, 0);
         };
 
         // fragment read offsets inside a half-tile
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             const int cid = it * 512 + tid, r = cid >> 3, c = (cid & 7) ^ ((r >> 1) & 7);
             int gm = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
             gm = gm < M ? gm : M - 1;
-            aoff[h][it] = (uint32_t)gm * (uint32_t)lda + c * 8;
+            aoff[h][it] = ((uint32_t)gm * (uint32_t)lda + c * 8) * 2u;      // byte offsets (buffer_load ... lds voffset)
         }
     };
     auto set_boff = [&](int g, int n0) {
@@ -294,21 +300,21 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             const int cid = it * 512 + tid, r = cid >> 3, c = (cid & 7) ^ ((r >> 1) & 7);
             int gn = n0 + (r >> 5) * 64 + g * 32 + (r & 31);
             gn = gn < N ? gn : N - 1;
-            boff[g][it] = (uint32_t)gn * (uint32_t)ldw + c * 8;
+            boff[g][it] = ((uint32_t)gn * (uint32_t)ldw + c * 8) * 2u;
         }
     };
     char* const wave_dst = smem + wid * 1024;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, 0xffffffff, 0x00020000);      // see Gemm8Phase::run
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0xffffffff, 0x00020000);
     auto issue_a = [&](int h, int kc, int buf) {
-        const uint16_t* base = Ag + kc;
         char* dst = wave_dst + buf * BUF_BYTES + h * HALF_BYTES;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + aoff[h][0]), (lds_void_t*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + aoff[h][1]), (lds_void_t*)(dst + 8192), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)dst, 16, aoff[h][0], kc * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(dst + 8192), 16, aoff[h][1], kc * 2, 0, 0);
     };
     auto issue_b = [&](int g, int kc, int buf) {
-        const uint16_t* base = Wg + kc;
         char* dst = wave_dst + buf * BUF_BYTES + (2 + g) * HALF_BYTES;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + boff[g][0]), (lds_void_t*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(base + boff[g][1]), (lds_void_t*)(dst + 8192), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t*)dst, 16, boff[g][0], kc * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void_t*)(dst + 8192), 16, boff[g][1], kc * 2, 0, 0);
     };
     const int frow = lane & 15, fq = lane >> 4, sw = (lane >> 1) & 7;
     const int fo0 = frow * 128 + (((0 + fq) ^ sw) << 4), fo1 = frow * 128 + (((4 + fq) ^ sw) << 4);
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
         // interior -> interior tile steps move every source offset by a block-uniform amount
         const bool edge = (m0 + 256 > M) || (m0n + 256 > M);
         const bool nclamp = (n0 + 256 > N) || (n0n + 256 > N);
-        const uint32_t d_a = (uint32_t)(m0n - m0) * (uint32_t)lda, d_b = (uint32_t)(n0n - n0) * (uint32_t)ldw;
+        const uint32_t d_a = (uint32_t)(m0n - m0) * (uint32_t)lda * 2u, d_b = (uint32_t)(n0n - n0) * (uint32_t)ldw * 2u;      // bytes
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
