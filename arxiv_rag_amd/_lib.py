@@ -50,6 +50,10 @@ EXPORTS = {
     "arx_topk_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "arx_topk_search": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "arx_topk_i8_index_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "arx_topk_build_i8": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "arx_topk_search_i8": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "arx_topk_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "arx_topk_merge": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),

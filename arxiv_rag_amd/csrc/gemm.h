@@ -27,6 +27,18 @@ template <> struct Mfma<f16_t> {
     }
 };
 
+// int8 operands seen through the same byte geometry as the 2-byte types: a "row of K elements" of this type is a row of 2 K int8
+// values (128-byte k-tiles, 16-byte fragments = 16 consecutive k), multiplied by v_mfma_i32_16x16x64_i8; the f32x4 accumulator
+// registers carry the int32 sums bit for bit (zero is zero in both).  Used by the search pre-filter (search.hip).
+struct i8pair_t { uint16_t v; };
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <> struct Mfma<i8pair_t> {
+    using vec = i32x4;
+    static __device__ __forceinline__ f32x4 mma(vec a, vec b, f32x4 c) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, __builtin_bit_cast(i32x4, c), 0, 0, 0));
+    }
+};
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 

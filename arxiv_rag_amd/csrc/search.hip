@@ -70,6 +70,114 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
+// int8 PRE-FILTER (optional second representation of the shard, `arx_topk_build_i8`): pass A over int8 rows — half the bytes in the
+// HBM-bound regime, twice the MFMA rate in the matrix-bound one — with nothing given up: what it writes per (query, 64-row group) is
+// a rigorous UPPER BOUND on the true fp16 score of every row of the group, and the exact passes (select, fp32 rescoring of the fp16
+// rows, certificate) run unchanged on it.
+//   row x (fp16, exact) = s * x8 + e,  s = max|x| / 127,  x8 = rint(x / s),  |e_i| <= 0.5001 s      (quantize_rows_i8_kernel; the 0.0001
+//   absorbs the fp32 division).  For a query q = s_q q8 + f and a corpus row c = s_c c8 + e:
+//       q.c = s_q s_c (q8.c8) + q^.e + f.c^ + f.e ,   |q^.e| <= 0.5001 s_c |q^|_1 ,  |f.c^| <= 0.5001 s_q |c^|_1 ,  |f.e| <= 0.2501 D s_q s_c
+//   with |q^|_1 = s_q L1(q8), |c^|_1 = s_c L1(c8):   q.c <= s_q s_c ( q8.c8 + 0.5001 (L1(q8) + L1(c8)) + 0.2501 D ) =: ub.
+// q8.c8 is an exact int32 (|.| <= 127^2 D < 2^24: exact as fp32 too); the four fp32 operations that form ub are covered by a 2^-20
+// relative inflation.  The certificate then reads: every unscored row's TRUE score <= U; U < s_k - tau => the answer is exact.  With
+// unit rows the slack is ~0.026, so a few hundred groups per query reach the threshold and are rescored by the certificate's
+// exhaustive-by-threshold step (one block per query, all its waves) — a few per cent of the bytes the int8 pass saves.
+__global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __restrict__ X, int64_t n_rows, int D, int8_t* __restrict__ X8,
+                                                                float2* __restrict__ meta) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int per = D / 64;                       // D % 128 == 0: per even, <= 16 (D <= 1024)
+    float v[16];
+    float amax = 0.f;
+    const f16_t* x = X + row * D + lane * per;
+    for (int e = 0; e < per; e += 2) {
+        const uint32_t w2 = *reinterpret_cast<const uint32_t*>(x + e);
+        f16_t h0, h1;
+        __builtin_memcpy(&h0, &w2, 2); __builtin_memcpy(&h1, reinterpret_cast<const char*>(&w2) + 2, 2);
+        v[e] = (float)h0; v[e + 1] = (float)h1;
+        amax = fmaxf(amax, fmaxf(fabsf(v[e]), fabsf(v[e + 1])));
+    }
+    amax = wave_max(amax);
+    const float s = amax / 127.0f;                 // an all-zero row: s = 0, every x8 = 0, upper bound 0
+    const float inv_s = amax > 0.f ? 127.0f / amax : 0.f;
+    float l1 = 0.f;
+    int8_t* o = X8 + row * D + lane * per;
+    for (int e = 0; e < per; e += 2) {
+        const float q0 = fminf(fmaxf(rintf(v[e] * inv_s), -127.f), 127.f), q1 = fminf(fmaxf(rintf(v[e + 1] * inv_s), -127.f), 127.f);
+        l1 += fabsf(q0) + fabsf(q1);
+        const uint16_t pk = (uint16_t)((uint8_t)(int8_t)(int)q0) | (uint16_t)((uint16_t)(uint8_t)(int8_t)(int)q1 << 8);
+        *reinterpret_cast<uint16_t*>(o + e) = pk;
+    }
+    l1 = wave_sum(l1);
+    if (lane == 0) meta[row] = float2{s, l1};
+}
+
+template <int BM, bool GLDS>
+__global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* __restrict__ Q8, const float2* __restrict__ qmeta, int nq,
+                                                                  const int8_t* __restrict__ C8, const float2* __restrict__ cmeta,
+                                                                  int64_t n_rows, int D, int tiles_q, int tiles_n,
+                                                                  float* __restrict__ gmax, int64_t ldg) {
+    using ML = GemmMainloop<i8pair_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
+    static_assert(ML::TN == GROUP_ROWS, "one wave column = one group");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = xcd_remap(blockIdx.x, tiles_q * tiles_n);
+    const int tile_q = t % tiles_q, tile_n = t / tiles_q;
+    const int m0 = tile_q * BM;
+    const int64_t n0 = (int64_t)tile_n * 256;
+    const int Dh = D >> 1;                        // the int8 rows as rows of D/2 two-byte elements: the f16 kernel's byte geometry
+    const i8pair_t* Q = reinterpret_cast<const i8pair_t*>(Q8);
+    const i8pair_t* C = reinterpret_cast<const i8pair_t*>(C8);
+    f32x4 acc[ML::NI][ML::MI];
+    const int rows_here = (int)((n_rows - n0) < 256 ? (n_rows - n0) : 256);
+    if constexpr (BM == 256 && GLDS) {
+#ifdef ARX_STAMP
+        unsigned long long dummy_stamp;
+        Gemm8Phase<i8pair_t, 2>::run(Q, Dh, nq, C + n0 * Dh, Dh, rows_here, Dh, m0, 0, smem, acc, tile_q * 2, dummy_stamp);
+#else
+        Gemm8Phase<i8pair_t, 2>::run(Q, Dh, nq, C + n0 * Dh, Dh, rows_here, Dh, m0, 0, smem, acc, tile_q * 2);
+#endif
+    } else
+        ML::run(Q, Dh, nq, C + n0 * Dh, Dh, rows_here, Dh, m0, 0, smem, acc, tile_q * 2);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid / 4, wn = wid % 4;
+    if (wn * GROUP_ROWS >= rows_here) return;
+    const int64_t g = (n0 >> 6) + wn;
+    // this lane's 16 corpus rows: n0 + wn*64 + j*16 + (lane>>4)*4 + r   (acc[j][i][r]; rows past the shard repeat its last row, as the loads did)
+    float sc[ML::NI][4], lc[ML::NI][4];
+#pragma unroll
+    for (int j = 0; j < ML::NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int64_t n = n0 + wn * GROUP_ROWS + j * 16 + (lane >> 4) * 4 + r;
+            n = n < n_rows ? n : n_rows - 1;
+            const float2 cm = cmeta[n];
+            sc[j][r] = cm.x; lc[j][r] = cm.y;
+        }
+    const float dterm = 0.2501f * (float)D;
+#pragma unroll
+    for (int i = 0; i < ML::MI; ++i) {
+        const int m = m0 + wm * ML::TM + i * 16 + (lane & 15);
+        const float2 qm = qmeta[m < nq ? m : nq - 1];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < ML::NI; ++j) {
+            const i32x4 it = __builtin_bit_cast(i32x4, acc[j][i]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dot = (float)it[r];
+                float ub = (sc[j][r] * qm.x) * (dot + 0.5001f * (lc[j][r] + qm.y) + dterm);
+                ub += fabsf(ub) * 9.5367432e-7f + 1e-12f;
+                mx = fmaxf(mx, ub);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (lane < 16 && m < nq) gmax[g * ldg + m] = mx;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // sorted insert into a register-resident top-K list (score desc, id asc on ties; new element has the
 // larger id when scanning in increasing id order, so strict '>' keeps the earlier one first)
 template <int K>
@@ -222,8 +330,15 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
                                                       const f16_t* __restrict__ C, int64_t n_rows, int D, int k,
                                                       float* __restrict__ out_s, int64_t* __restrict__ out_i,
                                                       int64_t idx_base, float tau_scale, int debug_drop,
-                                                      unsigned long long* __restrict__ stats) {
+                                                      unsigned long long* __restrict__ stats,
+                                                      float* __restrict__ thr_out, int32_t* __restrict__ selg_out,
+                                                      const int32_t* __restrict__ only_if) {
+    // thr_out / selg_out (int8 pre-filter, small query batches): COLLECT mode — write the provisional top-k, the threshold s_k - tau
+    // and the K rescored groups, and leave the rest to collect_pairs / pair_rescore / merge_survivors (the in-block fallback below
+    // walks this query's gmax column from ONE CU: fine for the rare uncertified query, far too slow when every query needs it).
+    // only_if: run only for the queries it flags (the overflow re-run of that pipeline).
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (only_if && !only_if[blockIdx.x]) return;
     constexpr int NW = NT / 64;
     constexpr int K1 = K + 1;
     constexpr int R1 = (256 * K + NT - 1) / NT;              // candidates per lane in stage (1): nslices <= 256
@@ -345,11 +460,16 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const bool full = gi_[k - 1] >= 0;                    // k rows found
         const float thr = full ? gs[k - 1] - tau_scale * sh_qn : -INFINITY;
-        const bool flag = sh_u > -INFINITY && sh_u >= thr;     // something unscored might belong to the top-k
+        const bool collect = thr_out != nullptr;
+        const bool flag = !collect && sh_u > -INFINITY && sh_u >= thr;     // something unscored might belong to the top-k
         if (lane == 0) { sh_flag = flag ? 1 : 0; sh_thr = thr; }
         if (!flag && lane < k) {
             out_s[(int64_t)q * k + lane] = gs[lane];
             out_i[(int64_t)q * k + lane] = gi_[lane] >= 0 ? gi_[lane] + idx_base : -1;
+        }
+        if (collect) {
+            if (lane == 0) thr_out[q] = thr;
+            if (lane < K) selg_out[q * K + lane] = sel_g[lane];
         }
     }
     __syncthreads();
@@ -411,6 +531,92 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
     if (stats && lane == 0) {
         if (w == 0) atomicAdd(&stats[0], 1ull);
         if (extra) atomicAdd(&stats[1], extra);
+    }
+}
+
+// ---- int8 pre-filter, small query batches: the candidates beyond the K selected groups, in three coalesced / parallel steps ---------
+#define PAIR_CAP_PER_QUERY 4096      // (query, group) pairs kept per query of the batch; beyond it the query is re-run by the exhaustive kernel
+#define SURV_CAP 256                 // rows at or above the threshold kept per query
+
+// every group whose upper bound reaches a query's threshold and that was not rescored yet -> (query, group) pair list
+__global__ __launch_bounds__(256) void collect_pairs_kernel(const float* __restrict__ gmax, int64_t ldg, int64_t n_groups, int nq,
+                                                             const float* __restrict__ thr, const int32_t* __restrict__ selg, int K,
+                                                             unsigned long long* __restrict__ pairs, int cap, int* __restrict__ counters) {
+    __shared__ float sthr[128];
+    for (int i = threadIdx.x; i < nq; i += 256) sthr[i] = thr[i];
+    __syncthreads();
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_groups) return;
+    const float* row = gmax + g * ldg;
+    for (int q = 0; q < nq; ++q) {
+        if (!(row[q] >= sthr[q])) continue;
+        bool sel = false;
+        for (int j = 0; j < K; ++j) sel = sel || (selg[q * K + j] == (int32_t)g);
+        if (sel) continue;
+        const int p = atomicAdd(&counters[0], 1);
+        if (p < cap) pairs[p] = ((unsigned long long)q << 32) | (unsigned long long)(uint32_t)g;
+        else counters[1] = 1;
+    }
+}
+
+// one wave per pair: exact scores of the group's 64 rows (the same exact_row_score as everywhere), rows at or above the query's
+// threshold are appended to its survivor list
+__global__ __launch_bounds__(256) void pair_rescore_kernel(const unsigned long long* __restrict__ pairs, const int* __restrict__ counters, int cap,
+                                                            const f16_t* __restrict__ Q, const f16_t* __restrict__ C, int64_t n_rows, int D,
+                                                            const float* __restrict__ thr, float* __restrict__ surv_s,
+                                                            int64_t* __restrict__ surv_i, int* __restrict__ nsurv) {
+    const int lane = threadIdx.x & 63, l8 = lane & 7, rsub = lane >> 3, nch = D >> 3;
+    const int np = counters[0] < cap ? counters[0] : cap;
+    for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < np; p += gridDim.x * 4) {
+        const unsigned long long pr = pairs[p];
+        const int q = (int)(pr >> 32);
+        const int64_t g = (int64_t)(uint32_t)pr;
+        const float t = thr[q];
+        const f16_t* qrow = Q + (int64_t)q * D;
+        for (int r8 = 0; r8 < GROUP_ROWS; r8 += 8) {
+            const int64_t row = g * GROUP_ROWS + r8 + rsub;
+            const bool ok = row < n_rows;
+            const float a = exact_row_score(C + (ok ? row : 0) * D, qrow, nch, l8, ok);
+            if (l8 == 0 && ok && a >= t) {
+                const int sidx = atomicAdd(&nsurv[q], 1);
+                if (sidx < SURV_CAP) { surv_s[q * SURV_CAP + sidx] = a; surv_i[q * SURV_CAP + sidx] = row; }
+            }
+        }
+    }
+}
+
+// provisional top-k (from the K selected groups) + survivors -> final top-k; a query whose lists overflowed is flagged for the exhaustive re-run
+__global__ __launch_bounds__(256) void merge_survivors_kernel(float* __restrict__ out_s, int64_t* __restrict__ out_i, int nq, int k, int64_t idx_base,
+                                                               const float* __restrict__ surv_s, const int64_t* __restrict__ surv_i,
+                                                               const int* __restrict__ nsurv, const int* __restrict__ counters,
+                                                               int32_t* __restrict__ redo, unsigned long long* __restrict__ stats) {
+    __shared__ float ms[4][KMAX];
+    __shared__ int64_t mi[4][KMAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= nq) return;
+    const int n = nsurv[q];
+    const bool over = n > SURV_CAP || counters[1] != 0;
+    if (lane == 0) {
+        redo[q] = over ? 1 : 0;
+        if (stats) { if (over) atomicAdd(&stats[0], 1ull); if (q == 0) atomicAdd(&stats[1], (unsigned long long)counters[0]); }
+    }
+    if (over) return;
+    constexpr int R = SURV_CAP / 64 + 1;
+    float s[R]; int64_t id[R];
+#pragma unroll
+    for (int j = 0; j < R - 1; ++j) {
+        const int i = j * 64 + lane;
+        s[j] = i < n ? surv_s[q * SURV_CAP + i] : -INFINITY;
+        id[j] = i < n ? surv_i[q * SURV_CAP + i] : -1;
+    }
+    s[R - 1] = lane < k ? out_s[(int64_t)q * k + lane] : -INFINITY;
+    id[R - 1] = (lane < k && out_i[(int64_t)q * k + lane] >= 0) ? out_i[(int64_t)q * k + lane] - idx_base : -1;
+    wave_topk<R>(s, id, k, lane, ms[w], mi[w]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < k) {
+        out_s[(int64_t)q * k + lane] = ms[w][lane];
+        out_i[(int64_t)q * k + lane] = mi[w][lane] >= 0 ? mi[w][lane] + idx_base : -1;
     }
 }
 
@@ -478,8 +684,9 @@ __global__ __launch_bounds__(256) void fill_unit_rows_kernel(f16_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct TopkWs { int64_t stats, gmax, part_s, part_g, total; int64_t ldg; int nsplit; int64_t n_groups; };
-static TopkWs topk_layout(int64_t n_rows, int nq, int k) {
+struct TopkWs { int64_t stats, gmax, part_s, part_g, q8, qmeta, thr, selg, counters, nsurv, redo, pairs, surv_s, surv_i, total;
+                int64_t ldg; int nsplit; int64_t n_groups; };
+static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim) {
     TopkWs w;
     const int qb = nq < QBATCH_MAX ? nq : QBATCH_MAX;
     w.ldg = round_up64(qb, 64);
@@ -493,13 +700,23 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k) {
     w.gmax = take(w.n_groups * w.ldg * 4);
     w.part_s = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
     w.part_g = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
+    w.q8 = take(w.ldg * (int64_t)dim);                           // int8 pre-filter: the query batch quantised (small; always reserved)
+    w.qmeta = take(w.ldg * 8);
+    w.thr = take(128 * 4);                                       // int8 pre-filter, batches of <= 128 queries: candidate pipeline state (~6 MB)
+    w.selg = take(128 * KSEL_BIG * 4);
+    w.counters = take(256);                                      // [0] pairs, [1] overflow   (zeroed per batch together with nsurv, which follows)
+    w.nsurv = take(128 * 4);
+    w.redo = take(128 * 4);
+    w.pairs = take((int64_t)128 * PAIR_CAP_PER_QUERY * 8);
+    w.surv_s = take((int64_t)128 * SURV_CAP * 4);
+    w.surv_i = take((int64_t)128 * SURV_CAP * 8);
     w.total = o;
     return w;
 }
 
 extern "C" int64_t arx_topk_workspace_bytes(int64_t n_rows, int32_t n_queries, int32_t dim, int32_t k) {
     if (n_rows <= 0 || n_queries <= 0 || dim <= 0 || k <= 0 || k > KMAX) return -1;
-    return topk_layout(n_rows, n_queries, k).total;
+    return topk_layout(n_rows, n_queries, k, dim).total;
 }
 
 template <int BM, bool GLDS>
@@ -516,9 +733,43 @@ static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_row
     return ARX_OK;
 }
 
+template <int BM, bool GLDS>
+static int launch_groupmax_i8(const int8_t* Q8, const float2* qmeta, int nq, const int8_t* C8, const float2* cmeta, int64_t n_rows, int D,
+                              float* gmax, int64_t ldg, hipStream_t st) {
+    using ML = GemmMainloop<i8pair_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
+    auto kern = search_groupmax_i8_kernel<BM, GLDS>;
+    constexpr int smem_bytes = (BM == 256 && GLDS) ? Gemm8Phase<i8pair_t, 2>::STAGE_OFF : ML::SMEM_BYTES;
+    ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem_bytes));
+    const int tq = cdiv(nq, BM);
+    const int64_t tn = (n_rows + 255) / 256;
+    ARX_REQUIRE(tq * tn < (1ll << 31), "grid too large");
+    kern<<<(int)(tq * tn), 512, smem_bytes, st>>>(Q8, qmeta, nq, C8, cmeta, n_rows, D, tq, (int)tn, gmax, ldg);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
+static int64_t i8_meta_offset(int64_t n_rows, int dim) { return round_up64(n_rows * (int64_t)dim, 256); }
+
+extern "C" int64_t arx_topk_i8_index_bytes(int64_t n_rows, int32_t dim) {
+    if (n_rows <= 0 || dim <= 0 || dim % 128 != 0 || dim > 1024) return -1;
+    return i8_meta_offset(n_rows, dim) + n_rows * 8;
+}
+
+extern "C" int32_t arx_topk_build_i8(const void* corpus, int64_t n_rows, int32_t dim, void* index_i8, void* stream) {
+    ARX_REQUIRE(corpus && index_i8 && n_rows > 0, "bad args");
+    ARX_REQUIRE(dim % 128 == 0 && dim <= 1024, "int8 pre-filter: dim=%d must be a multiple of 128, <= 1024", dim);
+    const int64_t blocks = (n_rows + 3) / 4;
+    ARX_REQUIRE(blocks < (1ll << 31), "too many rows for one launch");
+    quantize_rows_i8_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)corpus, n_rows, dim, (int8_t*)index_i8,
+                                                                         (float2*)((char*)index_i8 + i8_meta_offset(n_rows, dim)));
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
 template <int K, int NT>
 static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D,
-                              int k, float* out_s, int64_t* out_i, int64_t idx_base, float tau_scale, int debug_drop, hipStream_t st) {
+                              int k, float* out_s, int64_t* out_i, int64_t idx_base, float tau_scale, int debug_drop, hipStream_t st,
+                              bool collect = false) {
     float* gmax = (float*)(ws + L.gmax);
     float* ps = (float*)(ws + L.part_s);
     int32_t* pg = (int32_t*)(ws + L.part_g);
@@ -536,20 +787,49 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
     auto kern = rescore_kernel<K, NT>;
     if (smem > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)kern, (int)smem));
     ProfScope psc(ARX_K_SEARCH_RESCORE, st);
+    unsigned long long* stats = (unsigned long long*)(ws + L.stats);
+    if (!collect) {
+        kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
+                                   debug_drop, stats, nullptr, nullptr, nullptr);
+        ARX_HIP_CHECK(hipGetLastError());
+        return ARX_OK;
+    }
+    // int8 pre-filter, <= 128 queries: provisional top-k + threshold, then the candidate pipeline, then (only for queries whose
+    // lists overflowed) the exhaustive kernel
+    float* thr = (float*)(ws + L.thr);
+    int32_t* selg = (int32_t*)(ws + L.selg);
+    int* counters = (int*)(ws + L.counters);
+    int* nsurv = (int*)(ws + L.nsurv);
+    int32_t* redo = (int32_t*)(ws + L.redo);
+    unsigned long long* pairs = (unsigned long long*)(ws + L.pairs);
+    float* surv_s = (float*)(ws + L.surv_s);
+    int64_t* surv_i = (int64_t*)(ws + L.surv_i);
+    ARX_HIP_CHECK(hipMemsetAsync(ws + L.counters, 0, (size_t)(L.nsurv - L.counters) + 128 * 4, st));
     kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
-                               debug_drop, (unsigned long long*)(ws + L.stats));
+                               debug_drop, nullptr, thr, selg, nullptr);
+    ARX_HIP_CHECK(hipGetLastError());
+    const int cap = nq * PAIR_CAP_PER_QUERY;
+    collect_pairs_kernel<<<(int)((L.n_groups + 255) / 256), 256, 0, st>>>(gmax, L.ldg, L.n_groups, nq, thr, selg, K, pairs, cap, counters);
+    ARX_HIP_CHECK(hipGetLastError());
+    pair_rescore_kernel<<<1024, 256, 0, st>>>(pairs, counters, cap, Q, C, n_rows, D, thr, surv_s, surv_i, nsurv);
+    ARX_HIP_CHECK(hipGetLastError());
+    merge_survivors_kernel<<<cdiv(nq, 4), 256, 0, st>>>(out_s, out_i, nq, k, idx_base, surv_s, surv_i, nsurv, counters, redo, stats);
+    ARX_HIP_CHECK(hipGetLastError());
+    kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
+                               debug_drop, stats, nullptr, nullptr, redo);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
 
-extern "C" int32_t arx_topk_search(const void* corpus, int64_t n_rows, const void* queries, int32_t n_queries, int32_t dim,
-                                   int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base, void* ws,
-                                   int64_t ws_bytes, void* stream) {
+static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_rows, const void* queries, int32_t n_queries, int32_t dim,
+                            int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base, void* ws,
+                            int64_t ws_bytes, void* stream) {
     ARX_REQUIRE(corpus && queries && out_scores && out_ids && ws, "null pointer argument");
+    ARX_REQUIRE(!index_i8 || (dim % 128 == 0 && dim <= 1024), "int8 pre-filter: dim=%d must be a multiple of 128, <= 1024", dim);
     ARX_REQUIRE(n_rows > 0 && n_queries > 0, "empty corpus or query set");
     ARX_REQUIRE(dim > 0 && dim % 64 == 0 && dim <= 8192, "dim=%d must be a multiple of 64", dim);
     ARX_REQUIRE(k > 0 && k <= KMAX, "k=%d out of range 1..%d", k, KMAX);
-    const TopkWs L = topk_layout(n_rows, n_queries, k);
+    const TopkWs L = topk_layout(n_rows, n_queries, k, dim);
     ARX_REQUIRE(ws_bytes >= L.total, "workspace too small: %lld < %lld", (long long)ws_bytes, (long long)L.total);
     hipStream_t st = (hipStream_t)stream;
     const f16_t* C = (const f16_t*)corpus;
@@ -568,7 +848,19 @@ extern "C" int32_t arx_topk_search(const void* corpus, int64_t n_rows, const voi
         const f16_t* Q = (const f16_t*)queries + (int64_t)q0 * dim;
         float* gmax = (float*)((char*)ws + L.gmax);
         int rc;
-        {
+        const bool use_i8 = index_i8 && nq <= 128;      // above that the pass is matrix-bound and the candidates' rescoring outweighs the bytes saved
+        if (use_i8) {                           // pass A over the int8 representation: upper bounds instead of scores, everything after it unchanged
+            int8_t* q8 = (int8_t*)((char*)ws + L.q8);
+            float2* qmeta = (float2*)((char*)ws + L.qmeta);
+            quantize_rows_i8_kernel<<<cdiv(nq, 4), 256, 0, st>>>(Q, nq, dim, q8, qmeta);
+            ARX_HIP_CHECK(hipGetLastError());
+            const int8_t* C8 = (const int8_t*)index_i8;
+            const float2* cmeta = (const float2*)((const char*)index_i8 + i8_meta_offset(n_rows, dim));
+            ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
+            rc = nq <= 64 ? launch_groupmax_i8<64, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, L.ldg, st)
+               : nq <= 128 ? launch_groupmax_i8<128, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, L.ldg, st)
+                           : launch_groupmax_i8<256, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, L.ldg, st);
+        } else {
         ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
 #ifdef ARX_DEV_VARIANTS
         if (!glds) {
@@ -586,12 +878,25 @@ extern "C" int32_t arx_topk_search(const void* corpus, int64_t n_rows, const voi
         int64_t* oi = out_ids + (int64_t)q0 * k;
         // rescore geometry (same-box A/B, r02): a 16-wave block per query is fastest while the blocks fit the chip at once
         // (0.10 vs 0.13 ms at <= 64 queries); 4-wave blocks, eight to a CU, when there are thousands (2.9 vs 5.4 ms per 10 k)
-        if (k > 10) rc = run_select_rescore<KSEL_BIG, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
-        else if (nq <= 128) rc = run_select_rescore<KSEL_SMALL, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
+        if (k > 10) rc = run_select_rescore<KSEL_BIG, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8);
+        else if (nq <= 128) rc = run_select_rescore<KSEL_SMALL, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8);
         else rc = run_select_rescore<KSEL_SMALL, 256>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
         if (rc != ARX_OK) return rc;
     }
     return ARX_OK;
+}
+
+extern "C" int32_t arx_topk_search(const void* corpus, int64_t n_rows, const void* queries, int32_t n_queries, int32_t dim,
+                                   int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base, void* ws,
+                                   int64_t ws_bytes, void* stream) {
+    return topk_search_impl(corpus, nullptr, n_rows, queries, n_queries, dim, k, out_scores, out_ids, idx_base, ws, ws_bytes, stream);
+}
+
+extern "C" int32_t arx_topk_search_i8(const void* corpus, const void* index_i8, int64_t n_rows, const void* queries, int32_t n_queries,
+                                      int32_t dim, int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base, void* ws,
+                                      int64_t ws_bytes, void* stream) {
+    ARX_REQUIRE(index_i8, "null int8 index");
+    return topk_search_impl(corpus, index_i8, n_rows, queries, n_queries, dim, k, out_scores, out_ids, idx_base, ws, ws_bytes, stream);
 }
 
 extern "C" int32_t arx_topk_stats(const void* ws, int64_t* flagged_queries, int64_t* extra_groups, void* stream) {

@@ -15,14 +15,30 @@ from . import _lib
 
 
 class ShardIndex:
-    def __init__(self, corpus_f16: torch.Tensor, idx_base: int = 0):
+    def __init__(self, corpus_f16: torch.Tensor, idx_base: int = 0, prefilter: Optional[str] = None):
+        """`prefilter="int8"` (dim % 128 == 0, <= 1024): also keep an int8 representation of the rows (+50 % memory) and run the first
+        pass of every search over it — the same exact top-k (`arx_topk_search_i8`), 1.4-1.7x the queries per second."""
         assert corpus_f16.is_cuda and corpus_f16.dtype == torch.float16 and corpus_f16.dim() == 2
         assert corpus_f16.stride(1) == 1 and corpus_f16.stride(0) == corpus_f16.shape[1], "corpus must be dense row-major"
+        assert prefilter in (None, "int8")
         self.lib = _lib.load()
         self.corpus = corpus_f16
         self.n_rows, self.dim = corpus_f16.shape
         self.idx_base = int(idx_base)
         self._ws: Optional[torch.Tensor] = None
+        self._i8: Optional[torch.Tensor] = None
+        if prefilter == "int8" and self.n_rows > 0:
+            self.build_int8()
+
+    def build_int8(self):
+        """(Re)build the int8 pre-filter from the current fp16 rows (call again after the rows change)."""
+        need = self.lib.arx_topk_i8_index_bytes(self.n_rows, self.dim)
+        if need < 0:
+            raise _lib.ArxError(f"int8 pre-filter needs dim % 128 == 0 and dim <= 1024 (dim={self.dim})")
+        if self._i8 is None or self._i8.numel() != need:
+            self._i8 = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
+        _lib.check(self.lib.arx_topk_build_i8(self.corpus.data_ptr(), self.n_rows, self.dim, self._i8.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "arx_topk_build_i8")
 
     def _workspace(self, nq: int, k: int) -> torch.Tensor:
         need = self.lib.arx_topk_workspace_bytes(self.n_rows, nq, self.dim, k)
@@ -46,9 +62,14 @@ class ShardIndex:
             scores.fill_(float("-inf")); ids.fill_(-1)
             return scores, ids
         ws = self._workspace(nq, k)
-        rc = self.lib.arx_topk_search(self.corpus.data_ptr(), self.n_rows, q.data_ptr(), nq, self.dim, k,
-                                      scores.data_ptr(), ids.data_ptr(), self.idx_base, ws.data_ptr(), ws.numel(),
-                                      torch.cuda.current_stream().cuda_stream)
+        if self._i8 is not None:
+            rc = self.lib.arx_topk_search_i8(self.corpus.data_ptr(), self._i8.data_ptr(), self.n_rows, q.data_ptr(), nq, self.dim, k,
+                                             scores.data_ptr(), ids.data_ptr(), self.idx_base, ws.data_ptr(), ws.numel(),
+                                             torch.cuda.current_stream().cuda_stream)
+        else:
+            rc = self.lib.arx_topk_search(self.corpus.data_ptr(), self.n_rows, q.data_ptr(), nq, self.dim, k,
+                                          scores.data_ptr(), ids.data_ptr(), self.idx_base, ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "arx_topk_search")
         return scores, ids
 

@@ -429,6 +429,38 @@ def main():
                                "passA_hbm_frac": round(passes_bytes / (gms / gn * 1e-3) / HBM_PEAK, 4),
                                "passA_tflops": round(2 * min(qb, 1024) * N * D / (gms / gn * 1e-3) / 1e12, 1),
                                "select_ms": round(p["search_select"][0] / reps, 3), "rescore_ms": round(p["search_rescore"][0] / reps, 3)}
+        # the same searches with the int8 pre-filter (ShardIndex(prefilter="int8"): first pass over an int8 copy of the rows that yields
+        # upper bounds; identical exact answers): QPS per Qb, and how much the certificate's exhaustive-by-threshold step had to rescore
+        res8 = None
+        if D % 128 == 0 and D <= 1024:
+            idx8 = ShardIndex(corpus, idx_base=rank * N, prefilter="int8")
+            res8 = {}
+            for qb in (1, 64, 256, nq_all):
+                qb = min(qb, nq_all)
+                reps = max(1, min(20, (2048 // qb) if qb < nq_all else 1))
+                s8, i8 = idx8.search_distributed(queries[:qb], 10)
+                s16, i16 = idx.search_distributed(queries[:qb], 10)
+                same_rows = float((i8 == i16).all(dim=1).float().mean().item())
+                _lib.prof_reset(); _lib.prof_enable(True)
+                barrier(); t0 = time.perf_counter()
+                for r in range(reps):
+                    q0 = (r * qb) % max(1, nq_all - qb + 1)
+                    idx8.search_distributed(queries[q0:q0 + qb], 10)
+                barrier(); dts = time.perf_counter() - t0
+                _lib.prof_enable(False)
+                if use_dist:
+                    tm = torch.tensor([dts], dtype=torch.float64, device=dev); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dts = float(tm.item())
+                p = _lib.prof_read()
+                gms, gn = p["search_groupmax"]
+                flagged, extra = idx8.certificate_stats()
+                res8[f"Qb={qb}"] = {"qps": round(reps * qb / dts, 1), "ms_per_batch": round(dts / reps * 1e3, 3),
+                                    "passA_ms_per_launch": round(gms / gn, 4), "passA_bytes_per_launch": N * D,
+                                    "passA_GBps": round(N * D / (gms / gn * 1e-3) / 1e9, 1),
+                                    "select_ms": round(p["search_select"][0] / reps, 3), "rescore_ms": round(p["search_rescore"][0] / reps, 3),
+                                    "extra_groups_rescored_per_query": round(extra / max(1, min(qb, 1024) if qb == nq_all else qb), 1),
+                                    "rows_identical_to_fp16_pass": same_rows}
+            del idx8
+            torch.cuda.empty_cache()
         # the same step from query TEXT lengths (16 synthetic token ids per query): encode on the small-batch schedule
         # (arx_encoder_set_low_latency, <= 256 token rows) into an fp16 device matrix, then the search above
         from_tokens = {}
@@ -453,6 +485,9 @@ def main():
         r64 = res.get("Qb=64") or next(iter(res.values()))
         straffic = tjson.get("search_groupmax64_hbm_bytes_per_launch")
         search = {"workload": f"{N} x {D} fp16 rows per rank, {nq_all} queries, k=10, world {world}", "results": res,
+                  "int8_prefilter": None if res8 is None else {
+                      "note": "same corpus + an int8 copy (dim + 8 bytes per row more): pass A reads the int8 rows and writes rigorous upper "
+                              "bounds; select / fp32 rescoring of the fp16 rows / certificate unchanged, answers identical", "results": res8},
                   "encode_plus_search": {"note": "queries given as 16 token ids each: encoder forward + top-10 search, GPU-synchronised wall time per batch",
                                          **from_tokens},
                   "roofline": {"kernel": "search_groupmax_kernel<64> (pass A at Qb=64)", "bound": "hbm",

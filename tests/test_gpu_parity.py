@@ -154,9 +154,9 @@ def test_encoder_capacity_and_arg_errors(hip):
     enc.close()
 
 
-def _check_search(C_, Q_, k, idx_base=0):
+def _check_search(C_, Q_, k, idx_base=0, prefilter=None):
     from arxiv_rag_amd.index import ShardIndex
-    s, i = ShardIndex(torch.from_numpy(C_).cuda(), idx_base=idx_base).search(torch.from_numpy(Q_).cuda(), k)
+    s, i = ShardIndex(torch.from_numpy(C_).cuda(), idx_base=idx_base, prefilter=prefilter).search(torch.from_numpy(Q_).cuda(), k)
     s, i = s.cpu().numpy(), i.cpu().numpy()
     # oracle with one extra candidate to measure the k-th / (k+1)-th gap
     rs, ri = SO.topk_search(C_, Q_, k + 1, idx_base=idx_base)
@@ -184,6 +184,72 @@ def test_search_golden_with_exact_ties(hip, golden_dir):
 def test_search_vs_oracle_shapes(hip, n, nq, d, k):
     """ragged sizes: n not a multiple of 64/256, every query-tile variant (<=64, <=128, >128, >1024), k > n."""
     _check_search(SO.unit_rows_f16(n, d, 3), SO.unit_rows_f16(nq, d, 4), k, idx_base=12345)
+
+
+@pytest.mark.parametrize("n,nq,d,k", [(5000, 77, 768, 10), (130, 3, 128, 10), (70000, 200, 384, 10), (3000, 300, 1024, 5),
+                                      (9000, 1500, 256, 10), (64, 1, 768, 1), (100000, 130, 768, 32), (1, 5, 128, 3)])
+def test_search_int8_prefilter_is_exact(hip, n, nq, d, k):
+    """`ShardIndex(prefilter="int8")` (arx_topk_search_i8): the first pass runs over int8 rows and yields UPPER BOUNDS; the answer must be
+    the oracle's exact top-k all the same — same shapes as the fp16 test (every query-tile variant, ragged row counts, k > n), and
+    bit-identical scores and ids to the fp16 pass of the same index."""
+    from arxiv_rag_amd.index import ShardIndex
+    Cm, Q = SO.unit_rows_f16(n, d, 3), SO.unit_rows_f16(nq, d, 4)
+    s8, i8, _, _ = _check_search(Cm, Q, k, idx_base=12345, prefilter="int8")
+    s16, i16 = ShardIndex(torch.from_numpy(Cm).cuda(), idx_base=12345).search(torch.from_numpy(Q).cuda(), k)
+    s16, i16 = s16.cpu().numpy(), i16.cpu().numpy()
+    same = (i8 == i16).all(axis=1)
+    assert same.mean() > 0.98                                  # (rows tied to 1e-6 may be taken in either order by the two selections)
+    assert np.array_equal(s8[same], s16[same])                  # same rows -> the same fp32 rescoring, bit for bit
+
+
+def test_search_int8_prefilter_adversarial_rows(hip):
+    """Rows on which int8 quantisation is at its worst — one huge coordinate (scale set by an outlier: every other coordinate rounds to
+    0 or +-1), near-duplicates of the query differing in a few low-order bits, rows of very different norms, all-zero rows — and
+    the planted near-tie corpus of the certificate test.  The bound must hold on each: exact answers, checked row by row."""
+    from arxiv_rag_amd.index import ShardIndex
+    rs = np.random.RandomState(77)
+    d, n = 256, 64 * 300
+    Cm = SO.unit_rows_f16(n, d, 31).astype(np.float32); Q = SO.unit_rows_f16(8, d, 32).astype(np.float32)
+    out = rs.choice(n, size=2000, replace=False)
+    Cm[out[:700], rs.randint(d, size=700)] = 3.0 * np.sign(rs.standard_normal(700))          # outlier coordinate
+    Cm[out[700:1000]] *= rs.uniform(0.01, 8.0, size=(300, 1))                                   # norms far from 1
+    Cm[out[1000:1100]] = 0.0
+    for j, r in enumerate(out[1100:1400]):                                                       # near-duplicates of queries
+        v = Q[j % 8].copy(); c = rs.randint(d, size=3); v[c] *= (1 + 2.0 ** -9 * rs.choice([-1, 1], size=3)); Cm[r] = v
+    Q[3, 5] = 2.5                                                                                # a query with an outlier coordinate too
+    Cm, Q = Cm.astype(np.float16), Q.astype(np.float16)
+    for k in (10, 32):
+        idx = ShardIndex(torch.from_numpy(Cm).cuda(), prefilter="int8")
+        s, i = idx.search(torch.from_numpy(Q).cuda(), k)
+        _assert_topk_valid(Cm, Q, s.cpu().numpy(), i.cpu().numpy(), k, tol=2e-6 * float(np.abs(Cm.astype(np.float32)).max()) ** 2 * 4)
+    Cn, Qn, planted = _near_tied_corpus(60)
+    idx = ShardIndex(torch.from_numpy(Cn).cuda(), idx_base=7, prefilter="int8")
+    s, i = idx.search(torch.from_numpy(Qn).cuda(), 10)
+    _assert_topk_valid(Cn, Qn, s.cpu().numpy(), i.cpu().numpy(), 10, idx_base=7)
+    assert set(i.cpu().numpy()[0].tolist()) <= {p + 7 for p in planted}
+
+
+def test_search_int8_prefilter_overflow_falls_back_to_the_exhaustive_kernel(hip):
+    """More candidate groups than the pre-filter's pair list holds (a corpus of 320 000 IDENTICAL rows: every one of the 5 000 groups
+    reaches every query's threshold, and every row survives it): the candidate pipeline flags the queries and the exhaustive kernel
+    answers them — ids 0..k-1 (ties -> lower row), and the counters say the slow path ran for every query."""
+    from arxiv_rag_amd.index import ShardIndex
+    Cm = np.tile(SO.unit_rows_f16(1, 128, 1), (64 * 5000, 1)); Q = SO.unit_rows_f16(3, 128, 2)
+    idx = ShardIndex(torch.from_numpy(Cm).cuda(), prefilter="int8")
+    s, i = idx.search(torch.from_numpy(Q).cuda(), 10)
+    flagged, _ = idx.certificate_stats()
+    assert np.array_equal(i.cpu().numpy(), np.tile(np.arange(10), (3, 1)))
+    ref = (Q.astype(np.float32) @ Cm[:1].astype(np.float32).T)
+    assert np.abs(s.cpu().numpy() - ref).max() < 1e-5
+    assert flagged >= 3
+    # a mixed case: survivors overflow for ONE query only (300 exact copies of it among random rows), the others take the fast pipeline
+    rs = np.random.RandomState(5)
+    Cr = SO.unit_rows_f16(64 * 600, 256, 9); Qr = SO.unit_rows_f16(5, 256, 10)
+    Cr[rs.choice(len(Cr), size=300, replace=False)] = Qr[2]
+    idx = ShardIndex(torch.from_numpy(Cr).cuda(), idx_base=50, prefilter="int8")
+    s, i = idx.search(torch.from_numpy(Qr).cuda(), 10)
+    _assert_topk_valid(Cr, Qr, s.cpu().numpy(), i.cpu().numpy(), 10, idx_base=50)
+    assert idx.certificate_stats()[0] >= 1
 
 
 def test_search_duplicate_rows_everywhere(hip):
