@@ -76,7 +76,9 @@ class ShardIndex:
     def certificate_stats(self) -> Tuple[int, int]:
         """(queries whose first selection could not be certified, extra 64-row groups rescored for them) of the LAST `search`
         on this index: the answer is exact either way (csrc/search.hip, rescore_kernel step 5); the counters say how often the
-        slow path ran.  Synchronises on the current stream."""
+        slow path ran.  With the int8 pre-filter on batches of <= 128 queries the pair is (queries whose candidate lists overflowed
+        and went to the exhaustive kernel, (query, group) candidates the pre-filter's bounds let through) instead.
+        Synchronises on the current stream."""
         import ctypes as C
         if self._ws is None:
             return (0, 0)
