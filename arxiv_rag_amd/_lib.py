@@ -13,7 +13,7 @@ _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("ARX_LIB", _HERE / "libarx_hip.so"))
 
 K_CLASSES = ["search_groupmax", "gemm_qkv", "gemm_oproj", "gemm_fc1", "gemm_fc2", "attention",
-             "layernorm", "embed", "pool", "search_select", "search_rescore"]
+             "layernorm", "embed", "pool", "search_select", "search_rescore", "gemm_raw"]
 
 
 class EncoderConfigC(C.Structure):
@@ -72,6 +72,9 @@ EXPORTS = {
     "arx_adjacent_cosine": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "arx_f32_to_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "arx_fill_unit_rows_f16": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_void_p]),
+    "arx_fill_unit_rows_f16_at": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_void_p]),
+    "arx_topk_set_debug": (C.c_int32, [C.c_float, C.c_int32]),
+    "arx_topk_set_i8_max_queries": (C.c_int32, [C.c_int32]),
     "arx_prof_enable": (C.c_int32, [C.c_int32]),
     "arx_prof_reset": (C.c_int32, []),
     "arx_prof_read": (C.c_int32, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),

@@ -402,22 +402,19 @@ extern "C" int32_t arx_gemm_bf16(const void* A, const void* W, const float* bias
         }
     }
 #endif
-    ProfScope ps(ARX_K_GEMM_FC1, st);
-    if (variant == 70) {          // small-batch path alone (tests / tuning): one process-lifetime workspace per device for this entry point
-        static float* ws[64] = {nullptr};
-        static std::mutex mu;
-        int dev = 0;
-        ARX_HIP_CHECK(hipGetDevice(&dev));
-        ARX_REQUIRE(dev >= 0 && dev < 64, "device ordinal %d", dev);
-        {
-            std::lock_guard<std::mutex> g(mu);
-            if (!ws[dev]) ARX_HIP_CHECK(hipMalloc((void**)&ws[dev], ARX_SMALL_WS_BYTES));
-        }
+    ProfScope ps(ARX_K_GEMM_RAW, st);       // its own class: a raw call has whatever shape the caller chose, not FFN-1's
+    if (variant == 70) {          // small-batch path alone (tests / tuning): a stream-ordered scratch for this call, released behind its kernels
+        float* ws = nullptr;
+        ARX_HIP_CHECK(hipMallocAsync((void**)&ws, ARX_SMALL_WS_BYTES, st));
+        int rc = ARX_ERR_ARG;
         switch (mode) {
-        case EPI_BIAS: return launch_gemm_small<EPI_BIAS>((const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, ws[dev], st);
-        case EPI_BIAS_GELU: return launch_gemm_small<EPI_BIAS_GELU>((const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, ws[dev], st);
-        case EPI_BIAS_RESID: return launch_gemm_small<EPI_BIAS_RESID>((const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, ws[dev], st);
+        case EPI_BIAS: rc = launch_gemm_small<EPI_BIAS>((const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, ws, st); break;
+        case EPI_BIAS_GELU: rc = launch_gemm_small<EPI_BIAS_GELU>((const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, ws, st); break;
+        case EPI_BIAS_RESID: rc = launch_gemm_small<EPI_BIAS_RESID>((const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, ws, st); break;
+        default: arx_set_error("unknown gemm mode %d", mode);
         }
+        (void)hipFreeAsync(ws, st);
+        return rc;
     }
     switch (mode) {
     case EPI_BIAS: return arx_launch_gemm<EPI_BIAS>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);

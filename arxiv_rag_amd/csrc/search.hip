@@ -534,42 +534,61 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
     }
 }
 
-// ---- int8 pre-filter, small query batches: the candidates beyond the K selected groups, in three coalesced / parallel steps ---------
-#define PAIR_CAP_PER_QUERY 4096      // (query, group) pairs kept per query of the batch; beyond it the query is re-run by the exhaustive kernel
+// ---- int8 pre-filter: the candidates beyond the K selected groups, in three coalesced / parallel steps ---------------------------------
+#define PAIR_CAP_PER_QUERY 4096      // (query, group) pairs kept per query; a query that needs more is re-run ALONE by the exhaustive kernel
 #define SURV_CAP 256                 // rows at or above the threshold kept per query
+// counters (ints): [0] pairs appended to the list, [1] spare, [2, 2 + QBATCH_MAX) pairs seen per query, [2 + QBATCH_MAX, 2 + 2 QBATCH_MAX)
+// per-query overflow flag.  Overflow is PER QUERY: every query appends at most PAIR_CAP_PER_QUERY pairs, so the shared list
+// (nq x PAIR_CAP_PER_QUERY slots) cannot overflow, and one clustered query whose bound lets thousands of groups through sends only itself
+// to the exhaustive kernel, not the whole batch.
+#define CNT_QCOUNT 2
+#define CNT_QOVER (2 + QBATCH_MAX)
+#define CNT_INTS (2 + 2 * QBATCH_MAX)
 
-// every group whose upper bound reaches a query's threshold and that was not rescored yet -> (query, group) pair list
+// every group whose upper bound reaches a query's threshold and that was not rescored yet -> (query, group) pair list.
+// Thread t of a block owns queries 4t .. 4t+3 (one 16-B load per group row: a wave reads 1 KB of the row, fully coalesced); the block
+// walks `gpb` consecutive groups.
 __global__ __launch_bounds__(256) void collect_pairs_kernel(const float* __restrict__ gmax, int64_t ldg, int64_t n_groups, int nq,
                                                              const float* __restrict__ thr, const int32_t* __restrict__ selg, int K,
-                                                             unsigned long long* __restrict__ pairs, int cap, int* __restrict__ counters) {
-    __shared__ float sthr[128];
-    for (int i = threadIdx.x; i < nq; i += 256) sthr[i] = thr[i];
-    __syncthreads();
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= n_groups) return;
-    const float* row = gmax + g * ldg;
-    for (int q = 0; q < nq; ++q) {
-        if (!(row[q] >= sthr[q])) continue;
-        bool sel = false;
-        for (int j = 0; j < K; ++j) sel = sel || (selg[q * K + j] == (int32_t)g);
-        if (sel) continue;
-        const int p = atomicAdd(&counters[0], 1);
-        if (p < cap) pairs[p] = ((unsigned long long)q << 32) | (unsigned long long)(uint32_t)g;
-        else counters[1] = 1;
+                                                             unsigned long long* __restrict__ pairs, int* __restrict__ counters, int gpb) {
+    const int q0 = threadIdx.x * 4;
+    if (q0 >= ldg) return;                                        // no barrier in this kernel
+    float t4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t4[j] = (q0 + j < nq) ? thr[q0 + j] : INFINITY;
+    const int64_t g0 = (int64_t)blockIdx.x * gpb;
+    const int64_t g1 = g0 + gpb < n_groups ? g0 + gpb : n_groups;
+    for (int64_t g = g0; g < g1; ++g) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(gmax + g * ldg + q0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (!(v[j] >= t4[j])) continue;
+            const int q = q0 + j;
+            bool sel = false;
+            for (int jj = 0; jj < K; ++jj) sel = sel || (selg[q * K + jj] == (int32_t)g);
+            if (sel) continue;
+            const int qc = atomicAdd(&counters[CNT_QCOUNT + q], 1);
+            if (qc < PAIR_CAP_PER_QUERY) {
+                const int p = atomicAdd(&counters[0], 1);
+                pairs[p] = ((unsigned long long)q << 32) | (unsigned long long)(uint32_t)g;
+            } else
+                counters[CNT_QOVER + q] = 1;
+        }
     }
 }
 
 // one wave per pair: exact scores of the group's 64 rows (the same exact_row_score as everywhere), rows at or above the query's
 // threshold are appended to its survivor list
-__global__ __launch_bounds__(256) void pair_rescore_kernel(const unsigned long long* __restrict__ pairs, const int* __restrict__ counters, int cap,
+__global__ __launch_bounds__(256) void pair_rescore_kernel(const unsigned long long* __restrict__ pairs, const int* __restrict__ counters,
                                                             const f16_t* __restrict__ Q, const f16_t* __restrict__ C, int64_t n_rows, int D,
                                                             const float* __restrict__ thr, float* __restrict__ surv_s,
                                                             int64_t* __restrict__ surv_i, int* __restrict__ nsurv) {
     const int lane = threadIdx.x & 63, l8 = lane & 7, rsub = lane >> 3, nch = D >> 3;
-    const int np = counters[0] < cap ? counters[0] : cap;
+    const int np = counters[0];
     for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < np; p += gridDim.x * 4) {
         const unsigned long long pr = pairs[p];
         const int q = (int)(pr >> 32);
+        if (counters[CNT_QOVER + q]) continue;                    // this query goes to the exhaustive kernel anyway (wave-uniform)
         const int64_t g = (int64_t)(uint32_t)pr;
         const float t = thr[q];
         const f16_t* qrow = Q + (int64_t)q * D;
@@ -585,7 +604,7 @@ __global__ __launch_bounds__(256) void pair_rescore_kernel(const unsigned long l
     }
 }
 
-// provisional top-k (from the K selected groups) + survivors -> final top-k; a query whose lists overflowed is flagged for the exhaustive re-run
+// provisional top-k (from the K selected groups) + survivors -> final top-k; a query whose OWN lists overflowed is flagged for the exhaustive re-run
 __global__ __launch_bounds__(256) void merge_survivors_kernel(float* __restrict__ out_s, int64_t* __restrict__ out_i, int nq, int k, int64_t idx_base,
                                                                const float* __restrict__ surv_s, const int64_t* __restrict__ surv_i,
                                                                const int* __restrict__ nsurv, const int* __restrict__ counters,
@@ -596,7 +615,7 @@ __global__ __launch_bounds__(256) void merge_survivors_kernel(float* __restrict_
     const int q = blockIdx.x * 4 + w;
     if (q >= nq) return;
     const int n = nsurv[q];
-    const bool over = n > SURV_CAP || counters[1] != 0;
+    const bool over = n > SURV_CAP || counters[CNT_QOVER + q] != 0;
     if (lane == 0) {
         redo[q] = over ? 1 : 0;
         if (stats) { if (over) atomicAdd(&stats[0], 1ull); if (q == 0) atomicAdd(&stats[1], (unsigned long long)counters[0]); }
@@ -661,10 +680,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
     return x ^ (x >> 31);
 }
-__global__ __launch_bounds__(256) void fill_unit_rows_kernel(f16_t* __restrict__ dst, int64_t n_rows, int D, uint64_t seed) {
+__global__ __launch_bounds__(256) void fill_unit_rows_kernel(f16_t* __restrict__ dst, int64_t n_rows, int D, uint64_t seed, int64_t row_base) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lrow >= n_rows) return;
+    const int64_t row = lrow + row_base;                  // the row's index in the whole corpus: what the values depend on
     float v[16];
     float sq = 0.f;
     const int per = D / 64;          // D % 128 == 0 -> per even, <= 16
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(256) void fill_unit_rows_kernel(f16_t* __restrict__
         sq += v[e] * v[e] + v[e + 1] * v[e + 1];
     }
     const float inv = rsqrtf(wave_sum(sq));
-    f16_t* out = dst + row * D + lane * per;
+    f16_t* out = dst + lrow * D + lane * per;
     for (int e = 0; e < per; ++e) out[e] = (f16_t)(v[e] * inv);
 }
 
@@ -702,14 +722,15 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim) {
     w.part_g = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
     w.q8 = take(w.ldg * (int64_t)dim);                           // int8 pre-filter: the query batch quantised (small; always reserved)
     w.qmeta = take(w.ldg * 8);
-    w.thr = take(128 * 4);                                       // int8 pre-filter, batches of <= 128 queries: candidate pipeline state (~6 MB)
-    w.selg = take(128 * KSEL_BIG * 4);
-    w.counters = take(256);                                      // [0] pairs, [1] overflow   (zeroed per batch together with nsurv, which follows)
-    w.nsurv = take(128 * 4);
-    w.redo = take(128 * 4);
-    w.pairs = take((int64_t)128 * PAIR_CAP_PER_QUERY * 8);
-    w.surv_s = take((int64_t)128 * SURV_CAP * 4);
-    w.surv_i = take((int64_t)128 * SURV_CAP * 8);
+    const int64_t qc = qb;                                       // int8 pre-filter: candidate pipeline state, sized by the internal query batch
+    w.thr = take(qc * 4);
+    w.selg = take(qc * KSEL_BIG * 4);
+    w.counters = take(CNT_INTS * 4);                             // see CNT_* (zeroed per batch together with nsurv, which follows)
+    w.nsurv = take(QBATCH_MAX * 4);
+    w.redo = take(qc * 4);
+    w.pairs = take(qc * PAIR_CAP_PER_QUERY * 8);
+    w.surv_s = take(qc * SURV_CAP * 4);
+    w.surv_i = take(qc * SURV_CAP * 8);
     w.total = o;
     return w;
 }
@@ -804,20 +825,40 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
     unsigned long long* pairs = (unsigned long long*)(ws + L.pairs);
     float* surv_s = (float*)(ws + L.surv_s);
     int64_t* surv_i = (int64_t*)(ws + L.surv_i);
-    ARX_HIP_CHECK(hipMemsetAsync(ws + L.counters, 0, (size_t)(L.nsurv - L.counters) + 128 * 4, st));
+    ARX_HIP_CHECK(hipMemsetAsync(ws + L.counters, 0, (size_t)(L.nsurv - L.counters) + QBATCH_MAX * 4, st));
     kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
                                debug_drop, nullptr, thr, selg, nullptr);
     ARX_HIP_CHECK(hipGetLastError());
-    const int cap = nq * PAIR_CAP_PER_QUERY;
-    collect_pairs_kernel<<<(int)((L.n_groups + 255) / 256), 256, 0, st>>>(gmax, L.ldg, L.n_groups, nq, thr, selg, K, pairs, cap, counters);
+    {
+        const int gpb = 64;                                          // groups per block: 64 x ldg x 4 B = 16-256 KB of gmax per block
+        collect_pairs_kernel<<<(int)((L.n_groups + gpb - 1) / gpb), 256, 0, st>>>(gmax, L.ldg, L.n_groups, nq, thr, selg, K, pairs, counters, gpb);
+    }
     ARX_HIP_CHECK(hipGetLastError());
-    pair_rescore_kernel<<<1024, 256, 0, st>>>(pairs, counters, cap, Q, C, n_rows, D, thr, surv_s, surv_i, nsurv);
+    pair_rescore_kernel<<<2048, 256, 0, st>>>(pairs, counters, Q, C, n_rows, D, thr, surv_s, surv_i, nsurv);
     ARX_HIP_CHECK(hipGetLastError());
     merge_survivors_kernel<<<cdiv(nq, 4), 256, 0, st>>>(out_s, out_i, nq, k, idx_base, surv_s, surv_i, nsurv, counters, redo, stats);
     ARX_HIP_CHECK(hipGetLastError());
     kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
                                debug_drop, stats, nullptr, nullptr, redo);
     ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
+// query batches of more than this take the fp16 pass even when an int8 index is given (tuning knob; see the measurement in DESIGN.md)
+#define I8_MAX_NQ_DEFAULT 128
+static int g_i8_max_nq = I8_MAX_NQ_DEFAULT;
+extern "C" int32_t arx_topk_set_i8_max_queries(int32_t n) {
+    g_i8_max_nq = n < 0 ? I8_MAX_NQ_DEFAULT : n;
+    return ARX_OK;
+}
+
+// test hooks (arx_topk_set_debug): the tolerance can only be WIDENED, never read from the environment
+static float g_dbg_tau_mult = 1.0f;
+static int g_dbg_drop = 0;
+extern "C" int32_t arx_topk_set_debug(float tau_mult, int32_t drop_best) {
+    ARX_REQUIRE(tau_mult >= 1.0f, "tau_mult=%g: the certificate tolerance may only be widened (>= 1)", (double)tau_mult);
+    g_dbg_tau_mult = tau_mult;
+    g_dbg_drop = drop_best ? 1 : 0;
     return ARX_OK;
 }
 
@@ -838,17 +879,15 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
     const bool glds = !(genv && genv[0] == '0');
 #endif
     // certificate tolerance (rescore_kernel step 5): eps_A + eps_B per unit of |q|_2, corpus rows of norm <= 1 + 2^-9
-    float tau_scale = (0.3125f * (float)dim + 4.0f) * 5.9604645e-8f * (1.0f + 1.0f / 512.0f);
-    if (const char* te = getenv("ARX_TOPK_TAU_SCALE")) tau_scale *= (float)atof(te);      // test hook: > 1 widens the net (1e9 = rescoring everything)
-    const char* de = getenv("ARX_TOPK_DEBUG_DROP");                                       // test hook: selection forgets the best group
-    const int debug_drop = (de && de[0] == '1') ? 1 : 0;
+    const float tau_scale = (0.3125f * (float)dim + 4.0f) * 5.9604645e-8f * (1.0f + 1.0f / 512.0f) * g_dbg_tau_mult;   // arx_topk_set_debug: >= 1
+    const int debug_drop = g_dbg_drop;
     ARX_HIP_CHECK(hipMemsetAsync((char*)ws + L.stats, 0, 16, st));
     for (int q0 = 0; q0 < n_queries; q0 += QBATCH_MAX) {
         const int nq = (n_queries - q0) < QBATCH_MAX ? (n_queries - q0) : QBATCH_MAX;
         const f16_t* Q = (const f16_t*)queries + (int64_t)q0 * dim;
         float* gmax = (float*)((char*)ws + L.gmax);
         int rc;
-        const bool use_i8 = index_i8 && nq <= 128;      // above that the pass is matrix-bound and the candidates' rescoring outweighs the bytes saved
+        const bool use_i8 = index_i8 && nq <= g_i8_max_nq;          // arx_topk_set_i8_max_queries
         if (use_i8) {                           // pass A over the int8 representation: upper bounds instead of scores, everything after it unchanged
             int8_t* q8 = (int8_t*)((char*)ws + L.q8);
             float2* qmeta = (float2*)((char*)ws + L.qmeta);
@@ -880,7 +919,7 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         // (0.10 vs 0.13 ms at <= 64 queries); 4-wave blocks, eight to a CU, when there are thousands (2.9 vs 5.4 ms per 10 k)
         if (k > 10) rc = run_select_rescore<KSEL_BIG, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8);
         else if (nq <= 128) rc = run_select_rescore<KSEL_SMALL, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8);
-        else rc = run_select_rescore<KSEL_SMALL, 256>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
+        else rc = run_select_rescore<KSEL_SMALL, 256>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8);
         if (rc != ARX_OK) return rc;
     }
     return ARX_OK;
@@ -918,13 +957,17 @@ extern "C" int32_t arx_topk_merge(const float* scores, const int64_t* ids, int32
     return ARX_OK;
 }
 
-extern "C" int32_t arx_fill_unit_rows_f16(void* dst, int64_t n_rows, int32_t dim, uint64_t seed, void* stream) {
-    ARX_REQUIRE(dst && n_rows > 0, "bad args");
+extern "C" int32_t arx_fill_unit_rows_f16_at(void* dst, int64_t n_rows, int32_t dim, uint64_t seed, int64_t row_base, void* stream) {
+    ARX_REQUIRE(dst && n_rows > 0 && row_base >= 0, "bad args");
     ARX_REQUIRE(dim % 128 == 0 && dim <= 1024, "dim=%d must be a multiple of 128, <= 1024", dim);
     const int64_t blocks = (n_rows + 3) / 4;
     ARX_REQUIRE(blocks < (1ll << 31), "too many rows for one launch");
-    fill_unit_rows_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((f16_t*)dst, n_rows, dim, seed);
+    fill_unit_rows_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((f16_t*)dst, n_rows, dim, seed, row_base);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
+}
+
+extern "C" int32_t arx_fill_unit_rows_f16(void* dst, int64_t n_rows, int32_t dim, uint64_t seed, void* stream) {
+    return arx_fill_unit_rows_f16_at(dst, n_rows, dim, seed, 0, stream);
 }
 

@@ -81,32 +81,133 @@ def _load_many(args: Tuple[List[str], float]) -> List[Dict]:
 PROCESS_POOL_MIN_FILES = 4096      # below this a spawn pool's start-up (~0.2 s per worker) costs more than it saves
 
 
-def load_chunks_parallel(output_dir: Path, min_quality: float = 0.8, num_workers: Optional[int] = None) -> List[Dict]:
-    """All `*.json` under the tree except `._*` (GEN:94-129).  Files are visited in SORTED order and
-    results concatenated in that order: the reference's imap_unordered order is not a contract, and a
-    deterministic order is what lets N ranks agree on the shard boundaries.  `json.load` holds the GIL, so a corpus-sized
-    tree (GEN:103 sizes its pool for 70 k files) is parsed by a process pool — `spawn` context, as GEN:611-616 sets, which is
-    also the only start method that is safe once the process has touched the GPU — fed contiguous slices of the sorted
-    list through ordered `imap`; small trees are read by a thread pool in-process."""
-    files = sorted(f for f in Path(output_dir).rglob("*.json") if not f.name.startswith("._"))
+def effective_cpus() -> int:
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota.  `mp.cpu_count()` reports every
+    logical CPU of the machine (256 on a GPU box whose one-GPU job is granted 16): pools sized from it oversubscribe the quota 16x."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def default_load_workers() -> int:
+    """GEN:103 (`int(cpu_count * 0.8)`) on the CPUs this process may use, shared among the ranks of this node."""
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    return max(1, int(effective_cpus() * 0.8) // local_world)
+
+
+def list_chunk_files(output_dir: Path) -> List[Path]:
+    """All `*.json` under the tree except `._*` (GEN:97-98), SORTED: the order every rank agrees on."""
+    return sorted(f for f in Path(output_dir).rglob("*.json") if not f.name.startswith("._"))
+
+
+def load_chunk_files(files: Sequence[Path], min_quality: float = 0.8, num_workers: Optional[int] = None) -> List[List[Dict]]:
+    """The kept chunks of each file, one list per file, in the order given.  `json.load` holds the GIL, so a corpus-sized list
+    (GEN:103 sizes its pool for 70 k files) is parsed by a process pool — `spawn` context, as GEN:611-616 sets, which is also the
+    only start method that is safe once the process has touched the GPU — fed contiguous slices through ordered `imap`; small
+    lists are read by a thread pool in-process."""
     if num_workers is None:
-        num_workers = max(1, int(mp.cpu_count() * 0.8))
-    print(f"Loading chunks from {len(files):,} files using {num_workers} workers...")
-    out: List[Dict] = []
+        num_workers = default_load_workers()
+    per_file: List[List[Dict]] = []
     if len(files) >= PROCESS_POOL_MIN_FILES and num_workers > 1:
         nproc = min(num_workers, 64, max(2, len(files) // 1024))
         step = 128
         jobs = [([str(f) for f in files[i:i + step]], min_quality) for i in range(0, len(files), step)]
         with mp.get_context("spawn").Pool(nproc) as pool:
-            for part in pool.imap(_load_many, jobs, chunksize=1):
-                out.extend(part)
+            for part in pool.imap(_load_many_per_file, jobs, chunksize=1):
+                per_file.extend(part)
     else:
-        with ThreadPoolExecutor(max_workers=min(num_workers, 64)) as ex:
-            for part in ex.map(lambda f: load_chunks_from_file(f, min_quality), files):
-                if part:
-                    out.extend(part)
+        with ThreadPoolExecutor(max_workers=max(1, min(num_workers, 64))) as ex:
+            per_file.extend(ex.map(lambda f: load_chunks_from_file(f, min_quality), files))
+    return per_file
+
+
+def _load_many_per_file(args: Tuple[List[str], float]) -> List[List[Dict]]:
+    paths, min_quality = args
+    return [load_chunks_from_file(Path(p), min_quality) for p in paths]
+
+
+def load_chunks_parallel(output_dir: Path, min_quality: float = 0.8, num_workers: Optional[int] = None) -> List[Dict]:
+    """All `*.json` under the tree except `._*` (GEN:94-129).  Files are visited in SORTED order and results concatenated in that
+    order: the reference's imap_unordered order is not a contract, and a deterministic order is what lets N ranks agree on the
+    shard boundaries."""
+    files = list_chunk_files(output_dir)
+    if num_workers is None:
+        num_workers = default_load_workers()
+    print(f"Loading chunks from {len(files):,} files using {num_workers} workers...")
+    out: List[Dict] = []
+    for part in load_chunk_files(files, min_quality, num_workers):
+        if part:
+            out.extend(part)
     print(f"Loaded {len(out):,} high-quality chunks (quality >= {min_quality})")
     return out
+
+
+class RankChunks:
+    """What ONE rank of an N-rank run holds of the corpus: the chunks of global rows [lo, hi) (its contiguous range of work quanta),
+    `total` = the corpus' chunk count.  Built by `load_chunks_for_rank`: the tree is parsed ONCE across the ranks, not once per rank."""
+
+    def __init__(self, chunks: List[Dict], lo: int, hi: int, total: int, files_total: int, files_parsed: int):
+        self.chunks, self.lo, self.hi, self.total = chunks, lo, hi, total
+        self.files_total, self.files_parsed = files_total, files_parsed
+
+
+def load_chunks_for_rank(output_dir: Path, min_quality: float, num_workers: Optional[int], chunks_per_worker: int,
+                         world: int, rank: int, gather_counts: Optional[Callable] = None) -> RankChunks:
+    """Per-rank loading (the reference loads the tree once, with one pool: GEN:94-129; N ranks each loading ALL of it would be N
+    parses and N copies of every chunk's text).  Rank r parses only its contiguous slice of the SORTED file list; an
+    `all_gather_object` of the per-file kept-chunk counts gives every rank the global row offset of every file (the order contract —
+    sorted files, chunks in file order — is unchanged); the rank's row range stays the range of work quanta the sharded dispatcher
+    assigns (`shard_range` over `ceil(total / chunks_per_worker)` quanta, so every quantum is the same set of chunks as in a
+    one-rank run), and the few files of a neighbouring slice that reach into that range are parsed here as well."""
+    files = list_chunk_files(output_dir)
+    f_lo, f_hi = shard_range(len(files), world, rank)
+    if num_workers is None:
+        num_workers = default_load_workers()
+    print(f"[rank {rank}] Loading chunks from files [{f_lo:,}, {f_hi:,}) of {len(files):,} using {num_workers} workers...")
+    mine = load_chunk_files(files[f_lo:f_hi], min_quality, num_workers)
+    counts_local = [len(c) for c in mine]
+    if gather_counts is None:
+        import torch.distributed as dist
+        def gather_counts(x):                                          # noqa: E306
+            out: List = [None] * world
+            dist.all_gather_object(out, x)
+            return out
+    counts: List[int] = [n for part in gather_counts(counts_local) for n in part]
+    assert len(counts) == len(files), "ranks disagree on the file list"
+    offsets = np.zeros(len(files) + 1, np.int64)
+    np.cumsum(counts, out=offsets[1:])
+    total = int(offsets[-1])
+    n_quanta = (total + chunks_per_worker - 1) // chunks_per_worker
+    q_lo, q_hi = shard_range(n_quanta, world, rank)
+    lo, hi = min(total, q_lo * chunks_per_worker), min(total, q_hi * chunks_per_worker)
+    chunks: List[Dict] = []
+    extra = 0
+    if hi > lo:
+        fa = int(np.searchsorted(offsets, lo, side="right")) - 1       # first file holding row lo
+        fb = int(np.searchsorted(offsets, hi, side="left"))            # one past the last file holding row hi - 1
+        need = [i for i in range(fa, fb) if counts[i] > 0]
+        outside = [i for i in need if not (f_lo <= i < f_hi)]
+        extra = len(outside)
+        fetched = dict(zip(outside, load_chunk_files([files[i] for i in outside], min_quality, num_workers))) if outside else {}
+        for i in need:
+            part = mine[i - f_lo] if f_lo <= i < f_hi else fetched[i]
+            a, b = max(lo, int(offsets[i])) - int(offsets[i]), min(hi, int(offsets[i + 1])) - int(offsets[i])
+            chunks.extend(part[a:b])
+    assert len(chunks) == hi - lo, (len(chunks), lo, hi)
+    print(f"[rank {rank}] parsed {f_hi - f_lo + extra} of {len(files)} files (own slice [{f_lo}, {f_hi}) + {extra} boundary files); "
+          f"holds chunks [{lo:,}, {hi:,}) of {total:,} (quality >= {min_quality})")
+    return RankChunks(chunks, lo, hi, total, len(files), f_hi - f_lo + extra)
 
 
 # --------------------------------------------------------------------------------------------- embed
@@ -171,12 +272,14 @@ def make_shard_sink(model, n_texts: int, chunks_per_worker: int, world: int, ran
 
 
 def _encode_quanta(texts: List[str], q_lo: int, q_hi: int, model_name: str, batch_size: int, chunks_per_worker: int,
-                   super_quanta: int = 32, sink: Optional[ShardSink] = None):
+                   super_quanta: int = 32, sink: Optional[ShardSink] = None, base: int = 0, total: Optional[int] = None):
     """Quanta [q_lo, q_hi) -> yields (qi, rows, err) exactly as `generate_embeddings_worker` would, but fast: a HIP sentence
     encoder gets `super_quanta` quanta per `encode()` call (rows do not depend on how texts are batched, so the result is the same;
     the tokenizer feeder and the 1024-sequence forwards then run at the device-bound rate instead of 200 texts at a time).  Any
     exception or row-count mismatch in a fast call falls back to the per-quantum worker, i.e. to the reference's policy
-    (sub-batch retry, per-item retry, zero rows; GEN:131-177)."""
+    (sub-batch retry, per-item retry, zero rows; GEN:131-177).  `texts` holds global rows [base, base + len(texts)) of a corpus of
+    `total` chunks (per-rank loading); quanta are numbered globally."""
+    total = len(texts) if total is None else total
     model = None
     try:
         model = get_worker_model(model_name)
@@ -186,23 +289,23 @@ def _encode_quanta(texts: List[str], q_lo: int, q_hi: int, model_name: str, batc
     qi = q_lo
     while qi < q_hi:
         qe = min(q_hi, qi + (super_quanta if fast else 1))
-        a, b = qi * chunks_per_worker, min(len(texts), qe * chunks_per_worker)
+        a, b = qi * chunks_per_worker, min(total, qe * chunks_per_worker)
         rows = None
         if fast:
             try:
                 extra = {"device_f16_out": sink.view(a, b)} if sink is not None else {}
-                rows = model.encode(texts[a:b], batch_size=batch_size, normalize_embeddings=True, show_progress_bar=False,
+                rows = model.encode(texts[a - base:b - base], batch_size=batch_size, normalize_embeddings=True, show_progress_bar=False,
                                     convert_to_numpy=True, convert_to_tensor=False, **extra)
                 if len(rows) != b - a:
                     rows = None
             except Exception:
                 rows = None
         for q in range(qi, qe):
-            qa, qb = q * chunks_per_worker, min(len(texts), (q + 1) * chunks_per_worker)
+            qa, qb = q * chunks_per_worker, min(total, (q + 1) * chunks_per_worker)
             if rows is not None:
                 yield (q, list(rows[qa - a:qb - a]), None)
             else:
-                res = generate_embeddings_worker((texts[qa:qb], model_name, batch_size, q))
+                res = generate_embeddings_worker((texts[qa - base:qb - base], model_name, batch_size, q))
                 if sink is not None:                     # fallback rows are host arrays: this quantum's shard rows are replaced
                     try:
                         sink.view(qa, qb).zero_()
@@ -280,23 +383,29 @@ def generate_embeddings_parallel(chunks: List[Dict], model_name: str = "all-mpne
 
 
 def generate_embeddings_sharded(chunks: List[Dict], model_name: str, batch_size: int = 200,
-                                chunks_per_worker: int = 500, sink: Optional[ShardSink] = None) -> Tuple[np.ndarray, int, int]:
+                                chunks_per_worker: int = 500, sink: Optional[ShardSink] = None,
+                                span: Optional[Tuple[int, int, int]] = None) -> Tuple[np.ndarray, int, int]:
     """Multi-rank form of the dispatcher: this rank encodes a contiguous range of quanta and KEEPS its rows
     (no exchange of embeddings: at ~5 M chunks x 768 that would be 15 GB per rank for nothing).
-    Returns (rows float32 [hi-lo, D], lo, hi) with row j <-> chunk lo + j; failed quanta are zero rows."""
+    Returns (rows float32 [hi-lo, D], lo, hi) with row j <-> chunk lo + j; failed quanta are zero rows.
+    `span = (lo, hi, total)`: `chunks` are only this rank's chunks, global rows [lo, hi) of `total` (`load_chunks_for_rank`);
+    without it `chunks` is the whole corpus."""
     texts = [c["text"] for c in chunks]
     dist = _dist()
     world = dist.get_world_size() if dist else 1
     rank = dist.get_rank() if dist else 0
-    n_quanta = (len(texts) + chunks_per_worker - 1) // chunks_per_worker
+    total = len(texts) if span is None else span[2]
+    base = 0 if span is None else span[0]
+    n_quanta = (total + chunks_per_worker - 1) // chunks_per_worker
     q_lo, q_hi = shard_range(n_quanta, world, rank)
-    lo, hi = min(len(texts), q_lo * chunks_per_worker), min(len(texts), q_hi * chunks_per_worker)
-    print(f"[rank {rank}] encoding chunks [{lo:,}, {hi:,}) of {len(texts):,} ({q_hi - q_lo} quanta)")
+    lo, hi = min(total, q_lo * chunks_per_worker), min(total, q_hi * chunks_per_worker)
+    assert span is None or (span[0], span[1]) == (lo, hi), "the rank's chunks are not the rows its quanta cover"
+    print(f"[rank {rank}] encoding chunks [{lo:,}, {hi:,}) of {total:,} ({q_hi - q_lo} quanta)")
     dim = get_worker_model(model_name).get_sentence_embedding_dimension()
     rows = np.zeros((hi - lo, dim), np.float32)
     errors = 0
-    for idx, got, err in _encode_quanta(texts, q_lo, q_hi, model_name, batch_size, chunks_per_worker, sink=sink):
-        a, b = idx * chunks_per_worker, min(len(texts), (idx + 1) * chunks_per_worker)
+    for idx, got, err in _encode_quanta(texts, q_lo, q_hi, model_name, batch_size, chunks_per_worker, sink=sink, base=base, total=total):
+        a, b = idx * chunks_per_worker, min(total, (idx + 1) * chunks_per_worker)
         if err or len(got) != b - a:
             errors += 1
             print(f"Warning: Batch {idx} produced {len(got)} of {b - a} embeddings; missing rows stay zero")
@@ -308,13 +417,18 @@ def generate_embeddings_sharded(chunks: List[Dict], model_name: str, batch_size:
 
 
 def save_embeddings_sharded(chunks: List[Dict], rows: np.ndarray, lo: int, hi: int,
-                            output_dir: str = "./embeddings_saved", out_dtype: str = "float64", prefetch=None):
+                            output_dir: str = "./embeddings_saved", out_dtype: str = "float64", prefetch=None,
+                            total: Optional[int] = None):
     """Same three files as save_embeddings_to_disk_fallback, written cooperatively: rank 0 creates embeddings.npy
-    (header + size), every rank stores its own row range through a memmap, rank 0 writes metadata/index."""
+    (header + size), every rank stores its own row range through a memmap, rank 0 writes metadata/index.
+    `total` given: `chunks` are only this rank's chunks (rows [lo, hi) of `total`); every rank then serialises ITS entries of
+    metadata.json into a fragment file (beside the GPU work, when a `MetadataPrefetch` was started for it) and rank 0 joins the
+    fragments in rank order — the same bytes `_dump_metadata` writes for the whole list."""
     dist = _dist()
     rank = dist.get_rank() if dist else 0
+    world = dist.get_world_size() if dist else 1
     out = Path(output_dir)
-    n, dim = len(chunks), rows.shape[1]
+    n, dim = (len(chunks) if total is None else total), rows.shape[1]
     if rank == 0:
         out.mkdir(parents=True, exist_ok=True)
         arr = np.lib.format.open_memmap(out / "embeddings.npy", mode="w+", dtype=np.dtype(out_dtype), shape=(n, dim))
@@ -326,11 +440,39 @@ def save_embeddings_sharded(chunks: List[Dict], rows: np.ndarray, lo: int, hi: i
     nbytes = arr.nbytes
     arr.flush()
     del arr
+    if total is not None:                                   # this rank's entries of metadata.json
+        frag = out / f"metadata.json.part{rank}"
+        if prefetch is None or not prefetch.take(chunks, frag):
+            _dump_metadata(chunks, frag, first_index=lo, fragment=True)
     if dist:
         dist.barrier()
     if rank == 0:
-        _write_metadata_and_index(chunks, out, n, dim, nbytes, prefetch)
-        print(f"✅ Saved {n:,} embeddings ({dim} dimensions) from {dist.get_world_size() if dist else 1} rank(s)")
+        if total is None:
+            _write_metadata_and_index(chunks, out, n, dim, nbytes, prefetch)
+        else:
+            _join_metadata_fragments(out, world)
+            print(f"✅ Saved metadata to {out / 'metadata.json'}")
+            _write_index(out, n, dim, nbytes)
+        print(f"✅ Saved {n:,} embeddings ({dim} dimensions) from {world} rank(s)")
+
+
+def _join_metadata_fragments(out: Path, world: int):
+    """metadata.json = "[\n" + the ranks' entry runs joined by ",\n" + "\n]" (what `_dump_metadata` writes for the whole list)."""
+    with open(out / "metadata.json", "wb") as fh:
+        first = True
+        for r in range(world):
+            frag = out / f"metadata.json.part{r}"
+            if frag.stat().st_size:
+                fh.write(b"[\n" if first else b",\n")
+                first = False
+                with open(frag, "rb") as src:
+                    while True:
+                        buf = src.read(1 << 24)
+                        if not buf:
+                            break
+                        fh.write(buf)
+            frag.unlink()
+        fh.write(b"[]" if first else b"\n]")
 
 
 # --------------------------------------------------------------------------------------------- write
@@ -357,24 +499,30 @@ def save_embeddings_to_disk_fallback(chunks: List[Dict], embeddings: Sequence, o
     print(f"   Total size: ~{nbytes / 1024 / 1024 / 1024:.2f} GB")
 
 
-def _dump_metadata(chunks: List[Dict], path: Path):
+def _dump_metadata(chunks: List[Dict], path: Path, first_index: int = 0, fragment: bool = False):
     """metadata.json, byte for byte what `json.dump(metadata, f, indent=2, ensure_ascii=False)` writes at GEN:292-306, but
     streamed one chunk at a time: the reference builds the whole list and its serialisation in RAM (the text of ~5 M chunks
-    twice over); here the peak is one entry."""
+    twice over); here the peak is one entry.  `fragment`: only the entries (joined by ",\n", no brackets) of chunks that are
+    rows first_index.. of the corpus — one rank's part of the file (`_join_metadata_fragments`)."""
     with open(path, "w", encoding="utf-8") as fh:
         if not chunks:
-            fh.write("[]")
+            fh.write("" if fragment else "[]")
             return
-        fh.write("[\n")
+        if not fragment:
+            fh.write("[\n")
         for i, ch in enumerate(chunks):
             m = ch.get("metadata", {})
-            item = {"chunk_id": ch.get("chunk_id", f"chunk_{i}"), "paper_id": m.get("paper_id"),
+            item = {"chunk_id": ch.get("chunk_id", f"chunk_{first_index + i}"), "paper_id": m.get("paper_id"),
                     "section": m.get("section"), "quality_score": m.get("quality_score"),
                     "text": ch["text"], "text_length": len(ch["text"])}
             body = json.dumps(item, indent=2, ensure_ascii=False)
             fh.write("  " + body.replace("\n", "\n  "))
-            fh.write(",\n" if i + 1 < len(chunks) else "\n")
-        fh.write("]")
+            if i + 1 < len(chunks):
+                fh.write(",\n")
+            elif not fragment:
+                fh.write("\n")
+        if not fragment:
+            fh.write("]")
 
 
 class MetadataPrefetch(threading.Thread):
@@ -382,15 +530,17 @@ class MetadataPrefetch(threading.Thread):
     GPU while the embeddings are being generated, into `<out>/metadata.json.partial`; the writer renames it into place at
     the point where the reference writes the file (GEN:300-311), or discards it when the run does not get that far."""
 
-    def __init__(self, chunks: List[Dict], output_dir: str = "./embeddings_saved"):
+    def __init__(self, chunks: List[Dict], output_dir: str = "./embeddings_saved", first_index: int = 0,
+                 fragment_of_rank: Optional[int] = None):
         super().__init__(daemon=True)
         self.chunks, self.out, self.ok = chunks, Path(output_dir), False
-        self.partial = self.out / "metadata.json.partial"
+        self.first_index, self.fragment = first_index, fragment_of_rank is not None
+        self.partial = self.out / ("metadata.json.partial" if fragment_of_rank is None else f"metadata.json.partial{fragment_of_rank}")
 
     def run(self):
         try:
             self.out.mkdir(parents=True, exist_ok=True)
-            _dump_metadata(self.chunks, self.partial)
+            _dump_metadata(self.chunks, self.partial, first_index=self.first_index, fragment=self.fragment)
             self.ok = True
         except Exception:                                              # noqa: BLE001  (the writer then serialises itself)
             self.ok = False
@@ -415,6 +565,10 @@ def _write_metadata_and_index(chunks: List[Dict], out: Path, n: int, dim: int, n
     if prefetch is None or not prefetch.take(chunks, out / "metadata.json"):
         _dump_metadata(chunks, out / "metadata.json")
     print(f"✅ Saved metadata to {out / 'metadata.json'}")
+    _write_index(out, n, dim, nbytes)
+
+
+def _write_index(out: Path, n: int, dim: int, nbytes: int):
     index = {"total_embeddings": n, "embedding_dimension": dim, "total_size_gb": nbytes / 1024 / 1024 / 1024}
     with open(out / "index.json", "w", encoding="utf-8") as fh:
         json.dump(index, fh, indent=2)
@@ -466,23 +620,32 @@ def store_in_chroma_batched(chunks: List[Dict], embeddings: Sequence, db_path: s
 
 # --------------------------------------------------------------------------------------------- search (added step)
 def search_queries(model, chunks: List[Dict], shard: "ShardSink", queries: List[str], top_k: int = 10,
-                   output_dir: str = "./embeddings_saved") -> List[Dict]:
+                   output_dir: str = "./embeddings_saved", chunk_base: int = 0) -> List[Dict]:
     """Brute-force cosine top-k (config.yaml:63-64 `top_k: 10`) over the rank's fp16 rows in HBM; with
     torchrun each rank holds the contiguous row shard it encoded and the partial top-k lists are
     all-gathered over RCCL and merged.  `shard` is the `ShardSink` the encode step filled: rows [lo, hi) are already where they
     will be searched and nothing is uploaded here; the queries are encoded straight into an fp16 device matrix.  (A consumer that
-    only has the `.npy` rows on disk builds a `store.HipCollection` instead.)"""
+    only has the `.npy` rows on disk builds a `store.HipCollection` instead.)  `chunks[j]` is row `chunk_base + j` of the corpus:
+    with per-rank loading a rank only knows the chunk ids of its own rows, so the ids of the merged hits are exchanged (one
+    `all_gather_object` of at most Q x k small entries)."""
     import torch
     from .index import ShardIndex
     dist = _dist()
     rank = dist.get_rank() if dist else 0
+    world = dist.get_world_size() if dist else 1
     dev = model.encoder.device
     qd = torch.empty((len(queries), model.get_sentence_embedding_dimension()), dtype=torch.float16, device=dev)
     model.encode(queries, batch_size=256, normalize_embeddings=True, convert_to_numpy=True, device_f16_out=qd, low_latency=True)
     # int8 pre-filter (same exact answers; +50 % shard memory, one quantisation pass): 1.5-1.7x the queries per second on small batches
     pre = "int8" if (shard.rows.shape[1] % 128 == 0 and shard.rows.shape[1] <= 1024 and shard.rows.shape[0] > 0) else None
-    s, i = ShardIndex(shard.rows, idx_base=shard.lo, prefilter=pre).search_distributed(qd, top_k)
+    s, i = ShardIndex(shard.rows, idx_base=shard.lo, prefilter=pre, adaptive=True).search_distributed(qd, top_k)
     s, i = s.cpu().numpy(), i.cpu().numpy()
+    names = {int(j): chunks[int(j) - chunk_base].get("chunk_id", f"chunk_{int(j)}")
+             for j in np.unique(i) if chunk_base <= j < chunk_base + len(chunks)}
+    if dist and world > 1:
+        parts: List = [None] * world
+        dist.all_gather_object(parts, names)
+        names = {k: v for part in parts for k, v in part.items()}
     results = []
     for qi, text in enumerate(queries):
         hits = []
@@ -490,8 +653,7 @@ def search_queries(model, chunks: List[Dict], shard: "ShardSink", queries: List[
             j = int(i[qi, r])
             if j < 0:
                 continue
-            hits.append({"rank": r + 1, "score": float(s[qi, r]), "index": j,
-                         "chunk_id": chunks[j].get("chunk_id", f"chunk_{j}")})
+            hits.append({"rank": r + 1, "score": float(s[qi, r]), "index": j, "chunk_id": names.get(j, f"chunk_{j}")})
         results.append({"query": text, "results": hits})
     if rank == 0:
         with open(Path(output_dir) / "search_results.json", "w", encoding="utf-8") as fh:
@@ -542,7 +704,7 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
         if not dist.is_initialized():
             backend = "nccl" if torch.cuda.is_available() else "gloo"
             dist.init_process_group(backend)
-    cpu_count = mp.cpu_count()
+    cpu_count = effective_cpus()                                # usable by this job (cgroup quota), not the machine's logical CPUs
     print("=" * 80)
     print("PARALLEL EMBEDDING GENERATION - MI355X")
     print("=" * 80)
@@ -551,14 +713,21 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
     print(f"  Model: {args.model}")
     print(f"  Min quality: {args.min_quality}")
     print(f"  Batch size: {args.batch_size}")
-    print(f"  Load workers: {args.load_workers or int(cpu_count * 0.8)}")
+    print(f"  Load workers: {args.load_workers or default_load_workers()}")
     print(f"  Store batch size: {args.store_batch_size}")
     print(f"  ChromaDB: {args.chroma_db}\n")
     meta_prefetch = None
     try:
         t_start = time.time()
-        chunks = load_chunks_parallel(input_dir, min_quality=args.min_quality, num_workers=args.load_workers)
-        if not chunks:
+        span = None
+        if world > 1:
+            # per-rank loading: every rank parses its slice of the sorted file list and ends up holding only the chunks it encodes
+            rc_ = load_chunks_for_rank(input_dir, args.min_quality, args.load_workers, args.chunks_per_worker, world, rank)
+            chunks, span, n_chunks = rc_.chunks, (rc_.lo, rc_.hi, rc_.total), rc_.total
+        else:
+            chunks = load_chunks_parallel(input_dir, min_quality=args.min_quality, num_workers=args.load_workers)
+            n_chunks = len(chunks)
+        if not n_chunks:
             print("No chunks found!")
             return 1
         load_time = time.time() - t_start
@@ -569,7 +738,11 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
         except (ImportError, FileNotFoundError, OSError, RuntimeError) as e:
             print(f"Error: embedding backend not available: {e}")
             return 1
-        if rank == 0:                        # metadata.json is serialised beside the GPU work; renamed into place by the writer
+        # metadata.json is serialised beside the GPU work (this rank's entries when the chunks are per rank); renamed into place by the writer
+        if span is not None:
+            meta_prefetch = MetadataPrefetch(chunks, "./embeddings_saved", first_index=span[0], fragment_of_rank=rank)
+            meta_prefetch.start()
+        elif rank == 0:
             meta_prefetch = MetadataPrefetch(chunks, "./embeddings_saved")
             meta_prefetch.start()
         t0 = time.time()
@@ -577,10 +750,10 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
         if args.queries:
             qs = [ln.strip() for ln in Path(args.queries).read_text(encoding="utf-8").splitlines() if ln.strip()]
         # the search step works on the rows where the encoder leaves them: an fp16 shard in this rank's HBM
-        sink = make_shard_sink(_model, len(chunks), args.chunks_per_worker, world, rank) if qs else None
+        sink = make_shard_sink(_model, n_chunks, args.chunks_per_worker, world, rank) if qs else None
         if world > 1:
             # one process per GPU: every rank encodes, keeps and writes its own contiguous row range
-            embeddings, lo, hi = generate_embeddings_sharded(chunks, args.model, args.batch_size, args.chunks_per_worker, sink=sink)
+            embeddings, lo, hi = generate_embeddings_sharded(chunks, args.model, args.batch_size, args.chunks_per_worker, sink=sink, span=span)
         else:
             embeddings = generate_embeddings_parallel(chunks, model_name=args.model, batch_size=args.batch_size,
                                                       num_workers=args.embedding_workers, chunks_per_worker=args.chunks_per_worker,
@@ -589,7 +762,7 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
         print(f"Embedding generation completed in {embedding_time:.1f} seconds ({embedding_time / 60:.1f} min)\n")
         if world > 1:
             save_embeddings_sharded(chunks, embeddings, lo, hi, output_dir="./embeddings_saved", out_dtype=args.out_dtype,
-                                    prefetch=meta_prefetch)
+                                    prefetch=meta_prefetch, total=n_chunks)
         elif rank == 0:
             print("Saving embeddings to disk as backup...")
             save_embeddings_to_disk_fallback(chunks, embeddings, output_dir="./embeddings_saved", out_dtype=args.out_dtype,
@@ -600,7 +773,7 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
             if sink is None:
                 print("⚠️  --queries needs the HIP encoder (the search step runs over the shard it leaves in HBM): skipped")
             else:
-                search_queries(_model, chunks, sink, qs, top_k=args.top_k)
+                search_queries(_model, chunks, sink, qs, top_k=args.top_k, chunk_base=span[0] if span else 0)
         store_time = 0.0
         if rank == 0 and not args.skip_chroma:
             try:
@@ -610,8 +783,9 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
                 print("Install with: pip install chromadb")
                 return 1
             t0 = time.time()
-            if world > 1:                       # rank 0 only holds its shard: ingest from the file all ranks just wrote
+            if world > 1:                       # rank 0 only holds its shard: ingest from the files all ranks just wrote
                 embeddings = np.load(Path("./embeddings_saved") / "embeddings.npy", mmap_mode="r")
+                chunks = load_chunks_parallel(input_dir, min_quality=args.min_quality, num_workers=args.load_workers)
             try:
                 store_in_chroma_batched(chunks, embeddings, db_path=args.chroma_db, collection_name=args.collection_name,
                                         batch_size=args.store_batch_size)
@@ -625,8 +799,8 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
         print("\n" + "=" * 80)
         print("EMBEDDING GENERATION COMPLETE")
         print("=" * 80)
-        print(f"Chunks processed: {len(chunks):,}")
-        print(f"Embeddings generated: {len(chunks) if world > 1 else len(embeddings):,}")
+        print(f"Chunks processed: {n_chunks:,}")
+        print(f"Embeddings generated: {n_chunks if world > 1 else len(embeddings):,}")
         if len(embeddings):
             print(f"Embedding dimensions: {len(embeddings[0])}")
         print(f"Stored in: {args.chroma_db}\n")

@@ -15,9 +15,13 @@ from . import _lib
 
 
 class ShardIndex:
-    def __init__(self, corpus_f16: torch.Tensor, idx_base: int = 0, prefilter: Optional[str] = None):
+    def __init__(self, corpus_f16: torch.Tensor, idx_base: int = 0, prefilter: Optional[str] = None, adaptive: bool = False):
         """`prefilter="int8"` (dim % 128 == 0, <= 1024): also keep an int8 representation of the rows (+50 % memory) and run the first
-        pass of every search over it — the same exact top-k (`arx_topk_search_i8`), 1.4-1.7x the queries per second."""
+        pass of every search over it — the same exact top-k (`arx_topk_search_i8`), 1.4-1.7x the queries per second on rows that
+        quantise well.  `adaptive=True` (the CLI and `HipCollection` pass it): the index reads the certificate counters after its
+        first searches (a 16-byte copy + stream sync each) and switches the pre-filter OFF for good when more than a quarter of a
+        batch's queries overflowed their candidate lists — clustered / outlier-heavy rows on which the int8 bound is too slack to
+        pay (answers are exact either way; this only picks the faster first pass)."""
         assert corpus_f16.is_cuda and corpus_f16.dtype == torch.float16 and corpus_f16.dim() == 2
         assert corpus_f16.stride(1) == 1 and corpus_f16.stride(0) == corpus_f16.shape[1], "corpus must be dense row-major"
         assert prefilter in (None, "int8")
@@ -27,11 +31,15 @@ class ShardIndex:
         self.idx_base = int(idx_base)
         self._ws: Optional[torch.Tensor] = None
         self._i8: Optional[torch.Tensor] = None
+        self._i8_version = -1
+        self._adaptive, self._i8_searches, self.prefilter_disabled = bool(adaptive), 0, False
         if prefilter == "int8" and self.n_rows > 0:
             self.build_int8()
 
     def build_int8(self):
-        """(Re)build the int8 pre-filter from the current fp16 rows (call again after the rows change)."""
+        """(Re)build the int8 pre-filter from the current fp16 rows.  `search` calls it by itself when the corpus tensor was written
+        to since the last build (torch's version counter): int8 values of rows that no longer exist are not upper bounds of anything,
+        and a certificate computed from them could certify a wrong answer."""
         need = self.lib.arx_topk_i8_index_bytes(self.n_rows, self.dim)
         if need < 0:
             raise _lib.ArxError(f"int8 pre-filter needs dim % 128 == 0 and dim <= 1024 (dim={self.dim})")
@@ -39,6 +47,7 @@ class ShardIndex:
             self._i8 = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
         _lib.check(self.lib.arx_topk_build_i8(self.corpus.data_ptr(), self.n_rows, self.dim, self._i8.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream), "arx_topk_build_i8")
+        self._i8_version = self.corpus._version
 
     def _workspace(self, nq: int, k: int) -> torch.Tensor:
         need = self.lib.arx_topk_workspace_bytes(self.n_rows, nq, self.dim, k)
@@ -62,7 +71,10 @@ class ShardIndex:
             scores.fill_(float("-inf")); ids.fill_(-1)
             return scores, ids
         ws = self._workspace(nq, k)
-        if self._i8 is not None:
+        use_i8 = self._i8 is not None and not self.prefilter_disabled
+        if use_i8 and self.corpus._version != self._i8_version:      # rows written since the int8 copy was made (ShardSink.put, the encoder)
+            self.build_int8()
+        if use_i8:
             rc = self.lib.arx_topk_search_i8(self.corpus.data_ptr(), self._i8.data_ptr(), self.n_rows, q.data_ptr(), nq, self.dim, k,
                                              scores.data_ptr(), ids.data_ptr(), self.idx_base, ws.data_ptr(), ws.numel(),
                                              torch.cuda.current_stream().cuda_stream)
@@ -71,13 +83,21 @@ class ShardIndex:
                                           scores.data_ptr(), ids.data_ptr(), self.idx_base, ws.data_ptr(), ws.numel(),
                                           torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "arx_topk_search")
+        if use_i8 and self._adaptive and nq <= 1024 and (self._i8_searches < 4 or self._i8_searches % 64 == 0):
+            flagged, _ = self.certificate_stats()
+            if flagged * 4 > nq:
+                import sys
+                print(f"[arx] int8 pre-filter switched off for this index: {flagged} of {nq} queries overflowed their candidate lists "
+                      f"(rows on which the int8 bound is too slack); the fp16 pass answers from here on", file=sys.stderr)
+                self.prefilter_disabled = True
+        self._i8_searches += 1 if use_i8 else 0
         return scores, ids
 
     def certificate_stats(self) -> Tuple[int, int]:
         """(queries whose first selection could not be certified, extra 64-row groups rescored for them) of the LAST `search`
         on this index: the answer is exact either way (csrc/search.hip, rescore_kernel step 5); the counters say how often the
-        slow path ran.  With the int8 pre-filter on batches of <= 128 queries the pair is (queries whose candidate lists overflowed
-        and went to the exhaustive kernel, (query, group) candidates the pre-filter's bounds let through) instead.
+        slow path ran.  Where the int8 pre-filter ran the pair is (queries whose OWN candidate lists overflowed and went to the
+        exhaustive kernel, (query, group) candidates the pre-filter's bounds let through) instead.
         Synchronises on the current stream."""
         import ctypes as C
         if self._ws is None:
@@ -135,10 +155,12 @@ def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, min(n_total, lo + per)
 
 
-def fill_unit_rows(n_rows: int, dim: int, seed: int, device="cuda:0") -> torch.Tensor:
-    """Synthetic corpus/queries generated directly in HBM (bench cfg 3)."""
+def fill_unit_rows(n_rows: int, dim: int, seed: int, device="cuda:0", row_base: int = 0) -> torch.Tensor:
+    """Synthetic corpus/queries generated directly in HBM (bench cfg 3).  `row_base`: this tensor is rows [row_base, row_base + n_rows)
+    of the corpus the seed defines — every rank of a sharded run fills its own slice of ONE corpus (bench cfg 4)."""
     lib = _lib.load()
     t = torch.empty((n_rows, dim), dtype=torch.float16, device=device)
-    _lib.check(lib.arx_fill_unit_rows_f16(t.data_ptr(), n_rows, dim, seed, torch.cuda.current_stream().cuda_stream),
-               "arx_fill_unit_rows_f16")
+    if n_rows > 0:
+        _lib.check(lib.arx_fill_unit_rows_f16_at(t.data_ptr(), n_rows, dim, seed, row_base, torch.cuda.current_stream(t.device).cuda_stream),
+                   "arx_fill_unit_rows_f16_at")
     return t

@@ -57,7 +57,8 @@ class HipCollection:
             s1 = min(hi, s0 + chunk_rows)
             shard[s0 - lo:s1 - lo] = torch.from_numpy(np.ascontiguousarray(embeddings[s0:s1], dtype=np.float16)).to(device)
         dim = int(shard.shape[1]) if shard.dim() == 2 else 0
-        self.index = ShardIndex(shard, idx_base=lo, prefilter="int8" if (dim % 128 == 0 and 0 < dim <= 1024 and shard.shape[0] > 0) else None)
+        self.index = ShardIndex(shard, idx_base=lo, prefilter="int8" if (dim % 128 == 0 and 0 < dim <= 1024 and shard.shape[0] > 0) else None,
+                                adaptive=True)
 
     @classmethod
     def from_disk(cls, input_dir, **kw) -> "HipCollection":

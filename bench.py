@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on rank 0.
 
+Launch: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` each process is one rank; called plainly as
+`python bench.py --gpus N` with N > 1 it starts those N ranks itself as child processes (before touching the GPU) and passes their
+output through.
+
 Step = one pass of the encode hot path over one batch: 1024 synthetic chunks x exactly 256 token ids
 (BASELINE.json configs[1]: all-mpnet-base-v2 shape, bf16 weights/activations, fp32 accumulate), ids already
 resident in HBM, output = unit-norm fp16 rows written into the rank's HBM corpus shard.
@@ -10,7 +14,9 @@ the encode path).  Extra objects on the same line:
                 recorded by the library on the launch stream during the timed region), vs 2.5 PFLOP/s bf16
   encode        whole-forward MFMA fraction + per-kernel-class time split
   search        QPS@top-10 over a 10 M x 768 fp16 shard per rank (configs[2]) at several query-batch sizes,
-                pass-A HBM roofline fraction; with N > 1 the per-shard partials are all-gathered over RCCL
+                pass-A HBM roofline fraction; with N > 1 the per-shard partials are all-gathered over RCCL;
+                search.strong_scaling = configs[3] (ONE 5 M-row corpus cut N ways, merged answer checked against a single index),
+                search.shard_625k = its per-rank slice at N = 8, search.d1024 = configs[4]'s per-rank slice (6.25 M x 1024)
   cpu_baseline  the numpy oracle (oracle/encoder_oracle.py) timed on this box's host cores on a bounded sample
 """
 from __future__ import annotations
@@ -56,23 +62,7 @@ def flops_per_chunk(cfg, S):
     return L * (8 * S * H * H + 4 * S * H * F + 4 * S * S * H)
 
 
-def effective_cpus() -> int:
-    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a one-GPU job a
-    share of the host, while os.cpu_count() reports every logical CPU of the machine)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        q, per = Path("/sys/fs/cgroup/cpu.max").read_text().split()
-        if q != "max":
-            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
-    except Exception:
-        try:
-            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
-            per = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
-            if q > 0:
-                n = min(n, max(1, int(q / per + 0.5)))
-        except Exception:
-            pass
-    return max(1, n)
+from arxiv_rag_amd.generate_embeddings_parallel import effective_cpus      # noqa: E402  (affinity mask capped by the cgroup quota; numpy only)
 
 
 def _cpu_fanout(model_name, cfg, sd, S, workers, budget_s, B=4, timeout_s=240.0):
@@ -239,6 +229,35 @@ def cpu_baseline(model_name, cfg, sd, S, budget_s=30.0):
     return out
 
 
+def relaunch_command(n_gpus: int, argv, port: int):
+    """The command `python bench.py --gpus N` (no RANK in the environment) re-issues: N ranks of THIS file under torch.distributed.run
+    on this node, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
+def needs_self_launch(n_gpus: int, environ) -> bool:
+    """True when this process is NOT already a rank of a torch.distributed.run launch and more than one rank is asked for
+    (ARX_BENCH_FORCE_LAUNCH=1 forces the child-launch path for N = 1 too: the one-GPU rehearsal of the N-rank start-up)."""
+    if "RANK" in environ:
+        return False
+    return n_gpus > 1 or environ.get("ARX_BENCH_FORCE_LAUNCH") == "1"
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    """Start the N ranks as CHILD processes — before this process has touched torch.cuda or HIP (a process that initialised the GPU must
+    never exec or be replaced) — pass their stdout through (rank 0 prints the one JSON line) and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, effective_cpus() // max(1, n_gpus))))
+    return subprocess.run(relaunch_command(n_gpus, argv, port), env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,7 +266,11 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--seq-len", type=int, default=256)
     ap.add_argument("--model", default="all-mpnet-base-v2")
-    ap.add_argument("--search-rows", type=int, default=10_000_000, help="corpus rows per rank (0 = skip search leg)")
+    ap.add_argument("--search-rows", type=int, default=10_000_000, help="configs[2]: corpus rows PER RANK, weak scaling (0 = skip)")
+    ap.add_argument("--search-total-rows", type=int, default=5_000_000,
+                    help="configs[3]: rows of ONE corpus cut across the ranks with shard_bounds, strong scaling (0 = skip)")
+    ap.add_argument("--d1024-rows", type=int, default=6_250_000,
+                    help="configs[4]'s per-rank slice: rows of a dim-1024 shard searched on one GPU (N = 1 only; 0 = skip)")
     ap.add_argument("--search-queries", type=int, default=10_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query-leg", action="store_true",
@@ -259,12 +282,14 @@ def main():
                     help="A/B: record HIP events around every kernel inside the timed region (the pre-change behaviour)")
     ap.add_argument("--cpu-budget", type=float, default=30.0)
     args = ap.parse_args()
+    if needs_self_launch(args.gpus, os.environ):              # `python bench.py --gpus N` as the driver calls it: start the ranks ourselves
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
     from arxiv_rag_amd import _lib, config as C
     from arxiv_rag_amd.encoder import HipEncoder
-    from arxiv_rag_amd.index import ShardIndex, fill_unit_rows
+    from arxiv_rag_amd.index import ShardIndex, fill_unit_rows, gather_partials, merge_partials, shard_bounds
     from arxiv_rag_amd.weights import seeded_state_dict
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -399,66 +424,70 @@ def main():
         del big
         torch.cuda.empty_cache()
 
-    # ---- search leg (configs[2]; with N > 1: shard per rank + RCCL all-gather of partial top-k) ----------
+    # ---- search legs ------------------------------------------------------------------------------------
+    lib = _lib.load()
+
+    def allmax(x):
+        if use_dist:
+            tm = torch.tensor([x], dtype=torch.float64, device=dev); dist.all_reduce(tm, op=dist.ReduceOp.MAX); return float(tm.item())
+        return x
+
+    def time_search(ix, queries, qb, n_rows, D, int8_bytes=False):
+        """QPS of `ix.search_distributed` (local top-k [+ all-gather + merge under a process group]) on batches of qb queries, and the
+        per-kernel split of the same calls (library events on the launch stream)."""
+        nq_all = queries.shape[0]
+        qb = min(qb, nq_all)
+        reps = max(1, min(20, (2048 // qb) if qb < nq_all else 1))
+        ix.search_distributed(queries[:qb], 10)                            # warm
+        _lib.prof_reset(); _lib.prof_classes(None); _lib.prof_enable(True)
+        barrier(); t0 = time.perf_counter()
+        for r in range(reps):
+            q0 = (r * qb) % max(1, nq_all - qb + 1)
+            ix.search_distributed(queries[q0:q0 + qb], 10)
+        barrier(); dts = allmax(time.perf_counter() - t0)
+        _lib.prof_enable(False)
+        p = _lib.prof_read()
+        gms, gn = p["search_groupmax"]
+        pass_bytes = n_rows * D * (1 if int8_bytes else 2)                 # the bytes of the pass that RAN (int8 rows or fp16 rows)
+        e = {"qps": round(reps * qb / dts, 1), "ms_per_batch": round(dts / reps * 1e3, 3),
+             "passA_ms_per_launch": round(gms / gn, 4), "passA_launches_per_batch": gn // reps,
+             "passA_hbm_GBps": round(pass_bytes / (gms / gn * 1e-3) / 1e9, 1),
+             "passA_hbm_frac": round(pass_bytes / (gms / gn * 1e-3) / HBM_PEAK, 4),
+             "passA_tops" if int8_bytes else "passA_tflops": round(2 * min(qb, 1024) * n_rows * D / (gms / gn * 1e-3) / 1e12, 1),
+             "select_ms": round(p["search_select"][0] / reps, 3), "rescore_ms": round(p["search_rescore"][0] / reps, 3)}
+        if int8_bytes:
+            e["passA_bytes_per_launch"] = pass_bytes
+        return e
+
     search = None
     if args.search_rows > 0:
+        # configs[2] (weak scaling with N > 1: every rank holds its own 10 M rows of ONE world x 10 M-row corpus)
         N, nq_all, D = args.search_rows, args.search_queries, cfg.hidden
-        corpus = fill_unit_rows(N, D, seed=7 + rank, device=dev)
+        corpus = fill_unit_rows(N, D, seed=7, device=dev, row_base=rank * N)
         queries = fill_unit_rows(nq_all, D, seed=11, device=dev)          # same on every rank
         idx = ShardIndex(corpus, idx_base=rank * N)
-        res = {}
-        for qb in (1, 64, 256, nq_all):
-            qb = min(qb, nq_all)
-            reps = max(1, min(20, (2048 // qb) if qb < nq_all else 1))
-            idx.search_distributed(queries[:qb], 10)                        # warm
-            _lib.prof_reset(); _lib.prof_enable(True)
-            barrier(); t0 = time.perf_counter()
-            for r in range(reps):
-                q0 = (r * qb) % max(1, nq_all - qb + 1)
-                s_, i_ = idx.search_distributed(queries[q0:q0 + qb], 10)
-            barrier(); dts = time.perf_counter() - t0
-            _lib.prof_enable(False)
-            if use_dist:
-                tm = torch.tensor([dts], dtype=torch.float64, device=dev); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dts = float(tm.item())
-            p = _lib.prof_read()
-            gms, gn = p["search_groupmax"]
-            passes_bytes = N * D * 2
-            res[f"Qb={qb}"] = {"qps": round(reps * qb / dts, 1), "ms_per_batch": round(dts / reps * 1e3, 3),
-                               "passA_ms_per_launch": round(gms / gn, 4), "passA_launches_per_batch": gn // reps,
-                               "passA_hbm_GBps": round(passes_bytes / (gms / gn * 1e-3) / 1e9, 1),
-                               "passA_hbm_frac": round(passes_bytes / (gms / gn * 1e-3) / HBM_PEAK, 4),
-                               "passA_tflops": round(2 * min(qb, 1024) * N * D / (gms / gn * 1e-3) / 1e12, 1),
-                               "select_ms": round(p["search_select"][0] / reps, 3), "rescore_ms": round(p["search_rescore"][0] / reps, 3)}
+        res = {f"Qb={min(qb, nq_all)}": time_search(idx, queries, qb, N, D) for qb in (1, 64, 256, nq_all)}
         # the same searches with the int8 pre-filter (ShardIndex(prefilter="int8"): first pass over an int8 copy of the rows that yields
-        # upper bounds; identical exact answers): QPS per Qb, and how much the certificate's exhaustive-by-threshold step had to rescore
+        # upper bounds; identical exact answers).  Every Qb is run WITH the int8 pass here (arx_topk_set_i8_max_queries lifted for the
+        # table; the library's default crossover is restored after it) so that the line shows where it pays; `default_policy` says
+        # which pass a default call takes at that Qb.
         res8 = None
         if D % 128 == 0 and D <= 1024:
             idx8 = ShardIndex(corpus, idx_base=rank * N, prefilter="int8")
             res8 = {}
             for qb in (1, 64, 256, nq_all):
                 qb = min(qb, nq_all)
-                reps = max(1, min(20, (2048 // qb) if qb < nq_all else 1))
+                _lib.check(lib.arx_topk_set_i8_max_queries(1 << 30))
                 s8, i8 = idx8.search_distributed(queries[:qb], 10)
                 s16, i16 = idx.search_distributed(queries[:qb], 10)
                 same_rows = float((i8 == i16).all(dim=1).float().mean().item())
-                _lib.prof_reset(); _lib.prof_enable(True)
-                barrier(); t0 = time.perf_counter()
-                for r in range(reps):
-                    q0 = (r * qb) % max(1, nq_all - qb + 1)
-                    idx8.search_distributed(queries[q0:q0 + qb], 10)
-                barrier(); dts = time.perf_counter() - t0
-                _lib.prof_enable(False)
-                if use_dist:
-                    tm = torch.tensor([dts], dtype=torch.float64, device=dev); dist.all_reduce(tm, op=dist.ReduceOp.MAX); dts = float(tm.item())
-                p = _lib.prof_read()
-                gms, gn = p["search_groupmax"]
+                e = time_search(idx8, queries, qb, N, D, int8_bytes=True)
                 flagged, extra = idx8.certificate_stats()
-                res8[f"Qb={qb}"] = {"qps": round(reps * qb / dts, 1), "ms_per_batch": round(dts / reps * 1e3, 3),
-                                    "passA_ms_per_launch": round(gms / gn, 4), "passA_bytes_per_launch": N * D,
-                                    "passA_GBps": round(N * D / (gms / gn * 1e-3) / 1e9, 1),
-                                    "select_ms": round(p["search_select"][0] / reps, 3), "rescore_ms": round(p["search_rescore"][0] / reps, 3),
-                                    "extra_groups_rescored_per_query": round(extra / max(1, min(qb, 1024) if qb == nq_all else qb), 1),
-                                    "rows_identical_to_fp16_pass": same_rows}
+                _lib.check(lib.arx_topk_set_i8_max_queries(-1))
+                e.update({"candidate_groups_per_query": round(extra / max(1, min(qb, 1024)), 1), "queries_overflowed_in_last_pass": flagged,
+                          "rows_identical_to_fp16_pass": same_rows,
+                          "speedup_vs_fp16_pass": round(e["qps"] / res[f"Qb={qb}"]["qps"], 3)})
+                res8[f"Qb={qb}"] = e
         # the same step from query TEXT lengths (16 synthetic token ids per query): encode on the small-batch schedule
         # (arx_encoder_set_low_latency, <= 256 token rows) into an fp16 device matrix, then the search above
         from_tokens = {}
@@ -489,10 +518,12 @@ def main():
             torch.cuda.empty_cache()
         r64 = res.get("Qb=64") or next(iter(res.values()))
         straffic = tjson.get("search_groupmax64_hbm_bytes_per_launch")
-        search = {"workload": f"{N} x {D} fp16 rows per rank, {nq_all} queries, k=10, world {world}", "results": res,
+        search = {"workload": f"configs[2]: {N} x {D} fp16 rows per rank (rows [rank*N, (rank+1)*N) of one seeded corpus), {nq_all} queries, k=10, world {world}",
+                  "results": res,
                   "int8_prefilter": None if res8 is None else {
                       "note": "same corpus + an int8 copy (dim + 8 bytes per row more): pass A reads the int8 rows and writes rigorous upper "
-                              "bounds; select / fp32 rescoring of the fp16 rows / certificate unchanged, answers identical", "results": res8},
+                              "bounds; select / fp32 rescoring of the fp16 rows / certificate unchanged, answers identical.  Every row of this "
+                              "table ran the int8 pass (bytes and rates are that pass's)", "results": res8},
                   "encode_plus_search": {"note": "queries given as 16 token ids each: encoder forward + top-10 search, GPU-synchronised wall time per batch",
                                          **from_tokens},
                   "roofline": {"kernel": "search_groupmax_kernel<64> (pass A at Qb=64)", "bound": "hbm",
@@ -500,6 +531,90 @@ def main():
                                "frac": r64["passA_hbm_frac"], "traffic": straffic if N == 10_000_000 and D == 768 else None,
                                "bytes_per_launch": N * D * 2}}
         del corpus, idx
+        torch.cuda.empty_cache()
+
+    # ---- configs[3]: ONE corpus of --search-total-rows rows cut across the ranks (strong scaling), the query set replicated; every rank
+    # scans its own slice, one all-gather of the [Q, k] partials over RCCL, merge.  Rank 0 then searches the WHOLE corpus as a single
+    # index and checks the merged answer of the first 64 queries against it, bit for bit (the rows are a function of (seed, global row)).
+    if args.search_total_rows > 0:
+        NT_, nq_all, D = args.search_total_rows, args.search_queries, cfg.hidden
+        lo, hi = shard_bounds(NT_, world, rank)
+        queries = fill_unit_rows(nq_all, D, seed=11, device=dev)
+        shard_rows = fill_unit_rows(hi - lo, D, seed=7, device=dev, row_base=lo)
+        sidx = ShardIndex(shard_rows, idx_base=lo)
+        strong = {}
+        for qb in (64, 256, nq_all):
+            qb = min(qb, nq_all)
+            e = time_search(sidx, queries, qb, hi - lo, D)
+            e["passA_ms_at_hbm_roofline"] = round((hi - lo) * D * 2 / HBM_PEAK * 1e3, 4)
+            # the exchange step alone: all-gather of [qb, 10] scores + ids and the merge kernel
+            ps_, pi_ = sidx.search(queries[:qb], 10)
+            if use_dist:
+                gather_partials(ps_, pi_); barrier()
+                t0 = time.perf_counter()
+                for _ in range(20):
+                    a_s, a_i = gather_partials(ps_, pi_)
+                    merge_partials(a_s, a_i, 10)
+                barrier()
+                e["allgather_plus_merge_ms"] = round(allmax(time.perf_counter() - t0) / 20 * 1e3, 4)
+            strong[f"Qb={qb}"] = e
+        ms_, mi_ = sidx.search_distributed(queries[:64], 10)
+        check = None
+        if rank == 0:
+            try:
+                whole = fill_unit_rows(NT_, D, seed=7, device=dev) if world > 1 else shard_rows
+                ws_, wi_ = ShardIndex(whole).search(queries[:64], 10)
+                check = {"queries": 64, "ids_equal": bool(torch.equal(mi_, wi_)), "scores_equal": bool(torch.equal(ms_, ws_))}
+                del whole
+            except Exception as e_:                                        # noqa: BLE001
+                check = {"error": repr(e_)[:200]}
+        if search is None:
+            search = {}
+        search["strong_scaling"] = {
+            "workload": f"configs[3]: ONE corpus of {NT_} x {D} fp16 rows cut {world} way(s) ({hi - lo} rows on rank {rank}), {nq_all} queries "
+                        f"replicated, local top-10 -> all-gather of [Q,10] partials -> merge; qps includes the collective", "results": strong,
+            "merged_vs_single_index": check}
+        if world == 1 and NT_ >= 8:
+            # configs[3]'s PER-RANK slice on this one GPU: the 625 k-row shard rank 0 of an 8-way cut would hold (launch overheads, select
+            # and rescore are as long as the 0.12-ms pass here)
+            l8, h8 = shard_bounds(NT_, 8, 0)
+            sl = ShardIndex(shard_rows[l8:h8], idx_base=l8)
+            r625 = {}
+            for qb in (64, 256, nq_all):
+                qb = min(qb, nq_all)
+                e = time_search(sl, queries, qb, h8 - l8, D)
+                e["passA_ms_at_hbm_roofline"] = round((h8 - l8) * D * 2 / HBM_PEAK * 1e3, 4)
+                e["batch_frac_of_hbm_roofline"] = round(((h8 - l8) * D * 2 / HBM_PEAK * 1e3) * max(1, (qb + 1023) // 1024) / e["ms_per_batch"], 4)
+                r625[f"Qb={qb}"] = e
+            search["shard_625k"] = {"workload": f"rows [{l8}, {h8}) of the configs[3] corpus = one rank's slice of an 8-way cut, {D}-d, on one GPU",
+                                    "results": r625}
+            del sl
+        del sidx, shard_rows
+        torch.cuda.empty_cache()
+
+    # ---- configs[4]'s per-rank slice in the precision that is feasible (fp8 encode: measured infeasible at the 1e-3 bar):
+    # a 6.25 M x 1024 fp16 shard (12.8 GB) searched on one GPU
+    if args.d1024_rows > 0 and world == 1:
+        N4, D4 = args.d1024_rows, 1024
+        c4 = fill_unit_rows(N4, D4, seed=7, device=dev)
+        q4 = fill_unit_rows(2048, D4, seed=11, device=dev)
+        i4 = ShardIndex(c4)
+        r4 = {}
+        for qb in (1, 64, 256):
+            e = time_search(i4, q4, qb, N4, D4)
+            e["passA_ms_at_hbm_roofline"] = round(N4 * D4 * 2 / HBM_PEAK * 1e3, 4)
+            r4[f"Qb={qb}"] = e
+        i48 = ShardIndex(c4, prefilter="int8")
+        r48 = {}
+        for qb in (1, 64):
+            e = time_search(i48, q4, qb, N4, D4, int8_bytes=True)
+            r48[f"Qb={qb}"] = e
+        if search is None:
+            search = {}
+        search["d1024"] = {"workload": f"configs[4] per-rank slice: {N4} x {D4} fp16 rows (one of 8 shards of 50 M), 2048 queries, k=10, one GPU; "
+                                       f"bge-large encode in bf16: profiles/r03 (fp8 infeasible at the parity bar)",
+                           "results": r4, "int8_prefilter": r48}
+        del i4, i48, c4, q4
         torch.cuda.empty_cache()
 
     encode["sustained"] = sustained

@@ -168,6 +168,16 @@ int32_t arx_topk_search_i8(const void* corpus, const void* index_i8, int64_t n_r
  * counters say how often the slow path ran (near-duplicate chunks).  Copies 16 bytes to the host and waits on `stream`. */
 int32_t arx_topk_stats(const void* ws, int64_t* flagged_queries, int64_t* extra_groups, void* stream);
 
+/* Tuning knob of arx_topk_search_i8: query batches of more than `n` queries take the fp16 first pass even though an int8 index was
+ * given (0 = never use the int8 pass, a negative n restores the built-in default).  Answers are the same exact top-k either way; the default is the measured crossover. */
+int32_t arx_topk_set_i8_max_queries(int32_t n);
+
+/* TEST HOOKS of the certificate (no effect on a product run: both default to off and nothing in the package calls this).
+ * tau_mult >= 1 multiplies the certificate tolerance (1e9 = the fallback rescoring every group: an exhaustive exact scan); values below 1
+ * would SHRINK the tolerance and void the exactness guarantee, so they are refused.  drop_best != 0 makes the selection forget its best
+ * group, as a rounding accident at the boundary would: the certificate must recover it.  Process-wide; (1.0, 0) restores the defaults. */
+int32_t arx_topk_set_debug(float tau_mult, int32_t drop_best);
+
 /* Merge P partial top-k lists (e.g. the all-gathered per-shard results) into the global top-k.
  *   scores f32 [P, n_queries, k], ids int64 [P, n_queries, k] (device) -> out [n_queries, k]. */
 int32_t arx_topk_merge(const float* scores, const int64_t* ids, int32_t n_parts, int32_t n_queries,
@@ -215,6 +225,10 @@ int32_t arx_wp_version(void);
 int32_t arx_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* L2-normalised N(0,1) rows in fp16, generated on device from (seed, row index): bench cfg 3. */
 int32_t arx_fill_unit_rows_f16(void* dst, int64_t n_rows, int32_t dim, uint64_t seed, void* stream);
+/* The same generator for a row RANGE of a larger corpus: dst row j = row (row_base + j) of the corpus arx_fill_unit_rows_f16 would
+ * write for this seed — every rank of a sharded bench fills its own slice of ONE corpus (bench cfg 4: 5 M rows cut 8 ways), so that
+ * the merged answer can be checked against a single-index search of the same rows. */
+int32_t arx_fill_unit_rows_f16_at(void* dst, int64_t n_rows, int32_t dim, uint64_t seed, int64_t row_base, void* stream);
 
 /* ---- live per-kernel timing (bench.py roofline leg) ----------------------------------------------
  * When enabled, every launch of a hot kernel class is bracketed by hipEvents recorded on the launch
@@ -230,7 +244,8 @@ int32_t arx_fill_unit_rows_f16(void* dst, int64_t n_rows, int32_t dim, uint64_t 
 #define ARX_K_POOL            8
 #define ARX_K_SEARCH_SELECT   9
 #define ARX_K_SEARCH_RESCORE 10
-#define ARX_K_CLASSES        11
+#define ARX_K_GEMM_RAW       11    /* arx_gemm_bf16 called directly (unit tests, tuning): whatever its shape */
+#define ARX_K_CLASSES        12
 int32_t arx_prof_enable(int32_t on);
 /* bit c set = kernel class c (ARX_K_*) records its event pair while profiling is on (default: all).  A timed run enables only the
  * class it reports, so that the other ~170 event packets per forward do not sit between the kernels being timed. */

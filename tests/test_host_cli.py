@@ -431,6 +431,14 @@ def test_world_size_2_gloo_matches_single_process(tmp_path, tiny_model, world):
                         "--master-addr", "127.0.0.1", "--master-port", str(29615 + world), str(tmp_path / "w.py")],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "WORKER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    # per-rank loading: every rank parsed its own slice of the 6 files (+ the boundary files its quanta reach into), never the tree
+    parsed = {int(m.group(1)): (int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)))
+              for m in re.finditer(r"\[rank (\d+)\] parsed (\d+) of 6 files \(own slice \[(\d+), (\d+)\) \+ (\d+) boundary files\)", r.stdout)}
+    assert sorted(parsed) == list(range(world)), r.stdout[-3000:]
+    for rk, (n, a, b, extra) in parsed.items():
+        assert n == (b - a) + extra and (b - a) == len(range(*GEN.shard_range(6, world, rk)))
+    assert sum(v[0] for v in parsed.values()) < world * 6
+    assert not list((tmp_path / "out2" / "embeddings_saved").glob("metadata.json.part*"))      # fragments joined and removed
     cwd = os.getcwd()
     os.chdir(tmp_path / "out1")
     try:
@@ -441,6 +449,38 @@ def test_world_size_2_gloo_matches_single_process(tmp_path, tiny_model, world):
         os.chdir(cwd)
     for n in ("embeddings.npy", "metadata.json", "index.json"):
         assert (tmp_path / "out1" / "embeddings_saved" / n).read_bytes() == (tmp_path / "out2" / "embeddings_saved" / n).read_bytes(), n
+
+
+def test_per_rank_loading_opens_only_the_files_it_needs(tmp_path, monkeypatch):
+    """VERDICT r2 item 6 (GEN:94-129 loads the tree ONCE): with N ranks, rank r opens its contiguous slice of the sorted file list
+    plus the files of a neighbouring slice that hold rows of its quanta — nothing else; the ranks' chunks, concatenated in rank
+    order, are exactly the one-process list; the row ranges are the sharded dispatcher's; pools are sized from the cgroup quota."""
+    make_chunk_tree(tmp_path / "in", n_files=23, chunks_per_file=6, seed=3)
+    whole = GEN.load_chunks_parallel(tmp_path / "in", 0.9, 2)
+    files = GEN.list_chunk_files(tmp_path / "in")
+    per_file = [len(c) for c in GEN.load_chunk_files(files, 0.9, 2)]
+    offs = np.concatenate([[0], np.cumsum(per_file)])
+    assert sum(per_file) == len(whole) and 0 < len(whole) < 23 * 6              # the quality filter dropped some chunks
+    real = GEN.load_chunks_from_file
+    for world, cpw in ((3, 7), (8, 5), (2, 500)):
+        got, n_quanta = [], (len(whole) + cpw - 1) // cpw
+        for rank in range(world):
+            opened = []
+            monkeypatch.setattr(GEN, "load_chunks_from_file", lambda f, q, _o=opened: (_o.append(Path(f)), real(f, q))[1])
+            f_lo, f_hi = GEN.shard_range(len(files), world, rank)
+            counts = [[per_file[i] for i in range(*GEN.shard_range(len(files), world, r))] for r in range(world)]
+            rc = GEN.load_chunks_for_rank(tmp_path / "in", 0.9, 2, cpw, world, rank, gather_counts=lambda mine, _c=counts, _r=rank: (
+                _c.__setitem__(_r, mine), _c)[1])
+            monkeypatch.setattr(GEN, "load_chunks_from_file", real)
+            q_lo, q_hi = GEN.shard_range(n_quanta, world, rank)
+            assert (rc.lo, rc.hi, rc.total) == (min(len(whole), q_lo * cpw), min(len(whole), q_hi * cpw), len(whole))
+            want = set(files[f_lo:f_hi]) | {files[i] for i in range(len(files)) if per_file[i] and offs[i] < rc.hi and offs[i + 1] > rc.lo}
+            assert set(opened) == want and len(opened) == len(want) == rc.files_parsed
+            got.extend(rc.chunks)
+        assert got == whole
+    assert 1 <= GEN.default_load_workers() <= GEN.effective_cpus() <= (os.cpu_count() or 1)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert GEN.default_load_workers() == max(1, int(GEN.effective_cpus() * 0.8) // 8)
 
 
 # ------------------------------------------------------------------ on-disk layouts -> loader (SURVEY §8f row 2)
@@ -481,6 +521,22 @@ def test_semantic_grouping_matches_reference_walk():
     assert group_sentences([], []) == []
     with pytest.raises(ValueError):
         group_sentences(["a", "b"], [])
+
+
+def test_bench_starts_its_own_ranks_when_called_plainly():
+    """`python bench.py --gpus N` (how the driver calls it, no RANK in the environment) must launch N ranks itself; under
+    torch.distributed.run (RANK set) and for N = 1 it must not."""
+    import bench
+    assert bench.needs_self_launch(8, {}) and bench.needs_self_launch(2, {"WORLD_SIZE": "1"})
+    assert not bench.needs_self_launch(1, {})
+    assert not bench.needs_self_launch(8, {"RANK": "3", "WORLD_SIZE": "8"})
+    assert bench.needs_self_launch(1, {"ARX_BENCH_FORCE_LAUNCH": "1"})
+    cmd = bench.relaunch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], 29777)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29777"
+    i = cmd.index(str(ROOT / "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]          # the ranks get the caller's arguments unchanged
 
 
 def test_committed_bench_line_honours_the_contract():
