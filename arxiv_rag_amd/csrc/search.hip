@@ -23,6 +23,56 @@
 #define SUPER 16                      // groups per super-group in the selection pass
 #define SEL_SPLIT_WAVES 4            // waves per select block
 #define QBATCH_MAX 1024              // queries per internal pass (bounds the gmax workspace)
+#define CNT_QCOUNT 2                 // layout of the int8 candidate pipeline's counter block: see collect_pairs_kernel
+#define CNT_QOVER (2 + QBATCH_MAX)
+#define CNT_INTS (2 + 2 * QBATCH_MAX)
+
+// Reductions over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48 hold the same query) WITHOUT the LDS: v_permlane16_swap /
+// v_permlane32_swap of a value with itself leave, in every lane, the pair {own row's value, partner row's value} in the two
+// results (in an order that depends on the lane: use them symmetrically).  The ds_bpermute shuffles they replace are LDS round
+// trips in the tail of every pass-A block, where nothing overlaps them (0.15 ms per 39 k-block pass: profiles/r03).
+__device__ __forceinline__ void rows16(float x, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void rows32(float x, float& a, float& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float max_over_rows(float x) {
+    float a, b;
+    rows16(x, a, b); x = fmaxf(a, b);
+    rows32(x, a, b); return fmaxf(a, b);
+}
+__device__ __forceinline__ int min_over_rows(int x) {
+    auto r = __builtin_amdgcn_permlane16_swap((uint32_t)x, (uint32_t)x, false, false);
+    x = min((int)r[0], (int)r[1]);
+    r = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)x, false, false);
+    return min((int)r[0], (int)r[1]);
+}
+
+// After the row reduction the four 16-lane rows of a wave hold the SAME per-query results: v[i] = the value of query i*16 + (lane & 15),
+// i < MI.  Storing them from row 0 alone is MI store instructions of 64 B each — ten million 64-B writes per array and pass at 1 024
+// queries, which cost 1.2 ms of a 9.8-ms pass (profiles/r03, store probe).  Here row rr stores block i = rr + 4 k: one instruction
+// covers 64 consecutive queries = 256 contiguous bytes.
+template <int MI, typename V>
+__device__ __forceinline__ void store_query_row(V* __restrict__ dst, const V (&v)[MI], int m_first, int nq, int lane) {
+    const int rr = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < (MI + 3) / 4; ++k) {
+        V x = v[4 * k];
+#pragma unroll
+        for (int t = 1; t < 4; ++t)
+            if (4 * k + t < MI) {
+                V y = v[4 * k + t];
+                asm volatile("" : "+v"(y));          // opaque: keeps hipcc from turning the select chain into an indexed load of a SCRATCH copy of v
+                x = (rr == t) ? y : x;
+            }
+        const int i = 4 * k + rr;
+        const int m = m_first + i * 16 + (lane & 15);
+        if (i < MI && m < nq) dst[m] = x;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // pass A
@@ -55,6 +105,7 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
     const int wm = wid / 4, wn = wid % 4;
     if (wn * GROUP_ROWS >= rows_here) return;
     const int64_t g = (n0 >> 6) + wn;
+    float gm[ML::MI];
 #pragma unroll
     for (int i = 0; i < ML::MI; ++i) {
         float mx = -INFINITY;
@@ -62,11 +113,9 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
         for (int j = 0; j < ML::NI; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[j][i][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const int m = m0 + wm * ML::TM + i * 16 + (lane & 15);
-        if (lane < 16 && m < nq) gmax[g * ldg + m] = mx;
+        gm[i] = max_over_rows(mx);
     }
+    store_query_row<ML::MI, float>(gmax + g * ldg, gm, m0 + wm * ML::TM, nq, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -113,11 +162,23 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __re
     if (lane == 0) meta[row] = float2{s, l1};
 }
 
+// aux word per (query, group), beside the group's upper bound: the SECOND largest row bound of the group rounded UP to 16 bits (bf16
+// image, still an upper bound) in the high half, the position (0..63) of the row that holds the largest bound in the low bits.  When the
+// second bound is below a query's threshold, only that one row of the group can reach the top-k: the candidate step then reads ONE
+// fp16 row (1.5 KB at D = 768) instead of the group's 64 (98 KB) — on unit rows that is the case for all but a handful of the ~150
+// candidate groups per query, and it is what lets the int8 pass pay above the ridge point too (profiles/r03).
+__device__ __forceinline__ uint32_t pack_aux(float ub2, int arg_row) {
+    const uint32_t b = __float_as_uint(ub2);
+    const uint32_t up = (b & 0x80000000u) ? (b & 0xFFFF0000u)                      // negative: dropping mantissa bits moves towards zero = up
+                                          : ((b + 0xFFFFu) & 0xFFFF0000u);         // positive: round the magnitude up
+    return up | (uint32_t)(arg_row & 63);
+}
+
 template <int BM, bool GLDS>
 __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* __restrict__ Q8, const float2* __restrict__ qmeta, int nq,
                                                                   const int8_t* __restrict__ C8, const float2* __restrict__ cmeta,
                                                                   int64_t n_rows, int D, int tiles_q, int tiles_n,
-                                                                  float* __restrict__ gmax, int64_t ldg) {
+                                                                  float* __restrict__ gmax, uint32_t* __restrict__ aux, int64_t ldg) {
     using ML = GemmMainloop<i8pair_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
     static_assert(ML::TN == GROUP_ROWS, "one wave column = one group");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,6 +191,46 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
     const i8pair_t* C = reinterpret_cast<const i8pair_t*>(C8);
     f32x4 acc[ML::NI][ML::MI];
     const int rows_here = (int)((n_rows - n0) < 256 ? (n_rows - n0) : 256);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wm = wid / 4, wn = wid % 4;
+    // The row / query constants of the epilogue (scale and L1 norm of the tile's 256 corpus rows and BM queries: 2 KB + BM x 8 B) are
+    // requested BEFORE the main loop: loaded after it they are an exposed L2 round trip at the end of every tile, with nothing left to
+    // overlap it.  BM >= 128: by one 4-byte LDS-DMA per thread into 4 KB behind the k-tile buffers (no registers held across the loop;
+    // they are the oldest loads of the tile, retired by the loop's own waits and barriers).  BM = 64: the block must stay at 80 KB of
+    // LDS (two blocks per CU), so the values ride in 36 registers, which that kernel can spare.
+    constexpr bool META_LDS = BM >= 128;
+    constexpr int MAIN_BYTES = (BM == 256 && GLDS) ? Gemm8Phase<i8pair_t, 2>::STAGE_OFF : ML::SMEM_BYTES;
+    float* const meta = reinterpret_cast<float*>(smem + MAIN_BYTES);          // [512] corpus (s, L1) pairs, then [2 BM] query pairs
+    const int lrow = (lane >> 4) * 4;
+    float2 cmr[META_LDS ? 1 : ML::NI][META_LDS ? 1 : 4], qmr[META_LDS ? 1 : ML::MI];
+    if constexpr (META_LDS) {
+        const int tid = threadIdx.x;
+        {
+            int64_t e = n0 * 2 + tid;                                          // dword index into cmeta; rows past the shard repeat its last row
+            const int64_t last = n_rows * 2 - 2 + (tid & 1);
+            e = e < last ? e : last;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const float*>(cmeta) + e), (lds_void_t*)(meta + (tid & ~63)), 4, 0, 0);
+        }
+        if (tid < 2 * BM) {                                                    // wave-uniform (BM is a multiple of 32)
+            int e = m0 * 2 + tid;
+            const int last = nq * 2 - 2 + (tid & 1);
+            e = e < last ? e : last;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const float*>(qmeta) + e), (lds_void_t*)(meta + 512 + (tid & ~63)), 4, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ML::NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int64_t n = n0 + wn * GROUP_ROWS + j * 16 + lrow + r;
+                cmr[j][r] = cmeta[n < n_rows ? n : n_rows - 1];
+            }
+#pragma unroll
+        for (int i = 0; i < ML::MI; ++i) {
+            const int m = m0 + wm * ML::TM + i * 16 + (lane & 15);
+            qmr[i] = qmeta[m < nq ? m : nq - 1];
+        }
+    }
     if constexpr (BM == 256 && GLDS) {
 #ifdef ARX_STAMP
         unsigned long long dummy_stamp;
@@ -139,42 +240,73 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
 #endif
     } else
         ML::run(Q, Dh, nq, C + n0 * Dh, Dh, rows_here, Dh, m0, 0, smem, acc, tile_q * 2);
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int wm = wid / 4, wn = wid % 4;
     if (wn * GROUP_ROWS >= rows_here) return;
     const int64_t g = (n0 >> 6) + wn;
-    // this lane's 16 corpus rows: n0 + wn*64 + j*16 + (lane>>4)*4 + r   (acc[j][i][r]; rows past the shard repeat its last row, as the loads did)
-    float sc[ML::NI][4], lc[ML::NI][4];
-#pragma unroll
-    for (int j = 0; j < ML::NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int64_t n = n0 + wn * GROUP_ROWS + j * 16 + (lane >> 4) * 4 + r;
-            n = n < n_rows ? n : n_rows - 1;
-            const float2 cm = cmeta[n];
-            sc[j][r] = cm.x; lc[j][r] = cm.y;
-        }
+    // this lane's 16 corpus rows: n0 + wn*64 + j*16 + (lane>>4)*4 + r   (acc[j][i][r])
+    // ub(q, c) = s_q * [ s_c * (dot + cq) + X_c ],  cq = ceil(0.5001 L1(q8)) (an integer: added to the exact int32 dot),
+    // X_c = s_c * (0.5001 L1(c8) + 0.2501 D) inflated by 2^-22 (its two roundings).  Three instructions per element (integer add,
+    // convert — exact below 2^24 —, ONE fma = one rounding of the exact value); s_q > 0 and the rounding allowance are monotone, so
+    // the group's two largest bounds are reduced FIRST and scaled / inflated afterwards, on two values instead of sixteen.
+    float sc[ML::NI][4], xc[ML::NI][4];
     const float dterm = 0.2501f * (float)D;
 #pragma unroll
+    for (int j = 0; j < ML::NI; ++j) {
+        float2 c4[4];
+        if constexpr (META_LDS) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(meta + (wn * GROUP_ROWS + j * 16 + lrow) * 2);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(meta + (wn * GROUP_ROWS + j * 16 + lrow) * 2 + 4);
+            c4[0] = float2{lo[0], lo[1]}; c4[1] = float2{lo[2], lo[3]}; c4[2] = float2{hi[0], hi[1]}; c4[3] = float2{hi[2], hi[3]};
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c4[r] = cmr[j][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[j][r] = c4[r].x;
+            const float x = c4[r].x * fmaf(0.5001f, c4[r].y, dterm);
+            xc[j][r] = fmaf(x, 2.4e-7f, x);
+        }
+    }
+    float gm[ML::MI];
+    uint32_t ga[ML::MI];
+#pragma unroll
     for (int i = 0; i < ML::MI; ++i) {
-        const int m = m0 + wm * ML::TM + i * 16 + (lane & 15);
-        const float2 qm = qmeta[m < nq ? m : nq - 1];
-        float mx = -INFINITY;
+        float2 qm;
+        if constexpr (META_LDS) qm = *reinterpret_cast<const float2*>(meta + 512 + (wm * ML::TM + i * 16 + (lane & 15)) * 2);
+        else qm = qmr[i];
+        const int cqi = (int)ceilf(0.5001f * qm.y) + 1;
+        // top-2 of the 16 bounds with the arg-max for free: the low 6 bits of each value's float image are REPLACED by the row's
+        // position in the group (j*16 + r; the lane's 4-row offset is OR-ed in after the lane-local pass), which moves a value by at
+        // most 63 ulp either way — covered by the 2^-17 allowance below — and lets v_max / v_med3 carry the index along.
+        float m1 = -INFINITY, m2 = -INFINITY;
 #pragma unroll
         for (int j = 0; j < ML::NI; ++j) {
             const i32x4 it = __builtin_bit_cast(i32x4, acc[j][i]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float dot = (float)it[r];
-                float ub = (sc[j][r] * qm.x) * (dot + 0.5001f * (lc[j][r] + qm.y) + dterm);
-                ub += fabsf(ub) * 9.5367432e-7f + 1e-12f;
-                mx = fmaxf(mx, ub);
+                const float u = fmaf(sc[j][r], (float)(it[r] + cqi), xc[j][r]);
+                const float key = __uint_as_float((__float_as_uint(u) & ~63u) | (uint32_t)(j * 16 + r));
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, key);               // second largest of {m1 >= m2, key}
+                m1 = fmaxf(m1, key);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (lane < 16 && m < nq) gmax[g * ldg + m] = mx;
+        m1 = __uint_as_float(__float_as_uint(m1) | (uint32_t)lrow);
+        m2 = __uint_as_float(__float_as_uint(m2) | (uint32_t)lrow);
+        {
+            float a1, b1, a2, b2;
+            rows16(m1, a1, b1); rows16(m2, a2, b2);
+            m1 = fmaxf(a1, b1); m2 = fmaxf(fmaxf(a2, b2), fminf(a1, b1));
+            rows32(m1, a1, b1); rows32(m2, a2, b2);
+            m1 = fmaxf(a1, b1); m2 = fmaxf(fmaxf(a2, b2), fminf(a1, b1));
+        }
+        const int i1 = (int)(__float_as_uint(m1) & 63u);
+        float b1 = m1 * qm.x, b2 = m2 * qm.x;
+        b1 += fabsf(b1) * 8.0e-6f + 1e-12f;                              // 63 ulp of the index bits (2^-17.4) + the fma's and this product's roundings
+        b2 += fabsf(b2) * 8.0e-6f + 1e-12f;
+        gm[i] = b1; ga[i] = pack_aux(b2, i1);
     }
+    store_query_row<ML::MI, float>(gmax + g * ldg, gm, m0 + wm * ML::TM, nq, lane);
+    store_query_row<ML::MI, uint32_t>(aux + g * ldg, ga, m0 + wm * ML::TM, nq, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -249,8 +381,45 @@ __global__ __launch_bounds__(256) void select_groups_kernel(const float* __restr
     }
 }
 
-// Wave-synchronous top-k: every lane holds R candidates in registers; k rounds of (lane-local best, 6-step
-// shuffle arg-best, winner retires its candidate).  No LDS, no block barrier.  Order: score desc, id asc; id < 0 = empty.
+// All-reduce of the best (score desc, id asc) candidate over the 64 lanes WITHOUT the LDS: four DPP exchanges inside a 16-lane row
+// (quad permutes, half-row and row mirrors: every exchange pairs a lane with one that holds a different partial result, which is all an
+// all-reduce needs) and the two permlane swaps across rows.  Six steps of three register moves + a compare/select each; the
+// ds_bpermute form it replaces made 24 LDS round trips per extracted element, and a rescore block extracts ~55 of them one after the
+// other (profiles/r03: rescore 0.098 -> see DESIGN).  The order is total (ids are distinct; an empty slot is (-inf, INT64_MAX)), so both
+// partners of an exchange keep the same winner.
+__device__ __forceinline__ bool cand_better(float os, int64_t oi, float ws, int64_t wi) { return os > ws || (os == ws && oi < wi); }
+template <int CTRL>
+__device__ __forceinline__ void argbest_dpp(float& ws, int64_t& wi) {
+    const int s_ = __builtin_amdgcn_update_dpp(0, __float_as_int(ws), CTRL, 0xf, 0xf, true);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)wi, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((uint64_t)wi >> 32), CTRL, 0xf, 0xf, true);
+    const float os = __int_as_float(s_);
+    const int64_t oi = (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+    const bool take = cand_better(os, oi, ws, wi);
+    ws = take ? os : ws; wi = take ? oi : wi;
+}
+template <bool ROW32>
+__device__ __forceinline__ void argbest_rows(float& ws, int64_t& wi) {
+    const uint32_t s_ = __float_as_uint(ws), lo = (uint32_t)wi, hi = (uint32_t)((uint64_t)wi >> 32);
+    const auto rs = ROW32 ? __builtin_amdgcn_permlane32_swap(s_, s_, false, false) : __builtin_amdgcn_permlane16_swap(s_, s_, false, false);
+    const auto rl = ROW32 ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false) : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = ROW32 ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false) : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const float as = __uint_as_float(rs[0]), bs = __uint_as_float(rs[1]);
+    const int64_t ai = (int64_t)(((uint64_t)rh[0] << 32) | rl[0]), bi = (int64_t)(((uint64_t)rh[1] << 32) | rl[1]);
+    const bool take = cand_better(bs, bi, as, ai);
+    ws = take ? bs : as; wi = take ? bi : ai;
+}
+__device__ __forceinline__ void wave_argbest(float& ws, int64_t& wi) {
+    argbest_dpp<0xB1>(ws, wi);        // quad_perm [1,0,3,2]
+    argbest_dpp<0x4E>(ws, wi);        // quad_perm [2,3,0,1]
+    argbest_dpp<0x141>(ws, wi);       // row_half_mirror
+    argbest_dpp<0x140>(ws, wi);       // row_mirror
+    argbest_rows<false>(ws, wi);
+    argbest_rows<true>(ws, wi);
+}
+
+// Wave-synchronous top-k: every lane holds R candidates in registers; k rounds of (lane-local best, wave all-reduce of the best,
+// winner retires its candidate).  No LDS, no block barrier.  Order: score desc, id asc; id < 0 = empty.
 template <int R>
 __device__ __forceinline__ void wave_topk(float (&s)[R], int64_t (&id)[R], int k, int lane, float* out_s, int64_t* out_i) {
     for (int r = 0; r < k; ++r) {
@@ -258,16 +427,13 @@ __device__ __forceinline__ void wave_topk(float (&s)[R], int64_t (&id)[R], int k
 #pragma unroll
         for (int j = 0; j < R; ++j)
             if (id[j] >= 0 && (bj < 0 || s[j] > bs || (s[j] == bs && id[j] < bi))) { bs = s[j]; bi = id[j]; bj = j; }
-        float ws = bs; int64_t wi = bi; int wl = bj >= 0 ? lane : -1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float os = __shfl_xor(ws, o); const int64_t oi = __shfl_xor(wi, o); const int ol = __shfl_xor(wl, o);
-            if (ol >= 0 && (wl < 0 || os > ws || (os == ws && oi < wi))) { ws = os; wi = oi; wl = ol; }
-        }
+        float ws = bj >= 0 ? bs : -INFINITY; int64_t wi = bj >= 0 ? bi : INT64_MAX;
+        wave_argbest(ws, wi);
+        const bool found = wi != INT64_MAX;
 #pragma unroll
         for (int j = 0; j < R; ++j)
-            if (wl == lane && j == bj) id[j] = -1;
-        if (lane == 0) { out_s[r] = wl >= 0 ? ws : -INFINITY; out_i[r] = wl >= 0 ? wi : -1; }
+            if (found && j == bj && bi == wi) id[j] = -1;          // ids are distinct: only the winner's lane holds it
+        if (lane == 0) { out_s[r] = found ? ws : -INFINITY; out_i[r] = found ? wi : -1; }
     }
 }
 
@@ -332,7 +498,8 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
                                                       int64_t idx_base, float tau_scale, int debug_drop,
                                                       unsigned long long* __restrict__ stats,
                                                       float* __restrict__ thr_out, int32_t* __restrict__ selg_out,
-                                                      const int32_t* __restrict__ only_if) {
+                                                      const int32_t* __restrict__ only_if, int* __restrict__ cand_counters,
+                                                      int* __restrict__ cand_nsurv) {
     // thr_out / selg_out (int8 pre-filter, small query batches): COLLECT mode — write the provisional top-k, the threshold s_k - tau
     // and the K rescored groups, and leave the rest to collect_pairs / pair_rescore / merge_survivors (the in-block fallback below
     // walks this query's gmax column from ONE CU: fine for the rare uncertified query, far too slow when every query needs it).
@@ -468,7 +635,12 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
             out_i[(int64_t)q * k + lane] = gi_[lane] >= 0 ? gi_[lane] + idx_base : -1;
         }
         if (collect) {
-            if (lane == 0) thr_out[q] = thr;
+            if (lane == 0) {
+                thr_out[q] = thr;
+                // this query's candidate state for the steps that follow (no separate memset launch)
+                cand_counters[CNT_QCOUNT + q] = 0; cand_counters[CNT_QOVER + q] = 0; cand_nsurv[q] = 0;
+                if (q == 0) { cand_counters[0] = 0; cand_counters[1] = 0; }
+            }
             if (lane < K) selg_out[q * K + lane] = sel_g[lane];
         }
     }
@@ -537,52 +709,102 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
 // ---- int8 pre-filter: the candidates beyond the K selected groups, in three coalesced / parallel steps ---------------------------------
 #define PAIR_CAP_PER_QUERY 4096      // (query, group) pairs kept per query; a query that needs more is re-run ALONE by the exhaustive kernel
 #define SURV_CAP 256                 // rows at or above the threshold kept per query
-// counters (ints): [0] pairs appended to the list, [1] spare, [2, 2 + QBATCH_MAX) pairs seen per query, [2 + QBATCH_MAX, 2 + 2 QBATCH_MAX)
+// counters (ints): [0] (query, group) pairs appended, [1] (query, row) pairs appended, [2, 2 + QBATCH_MAX) pairs seen per query, [2 + QBATCH_MAX, 2 + 2 QBATCH_MAX)
 // per-query overflow flag.  Overflow is PER QUERY: every query appends at most PAIR_CAP_PER_QUERY pairs, so the shared list
 // (nq x PAIR_CAP_PER_QUERY slots) cannot overflow, and one clustered query whose bound lets thousands of groups through sends only itself
 // to the exhaustive kernel, not the whole batch.
-#define CNT_QCOUNT 2
-#define CNT_QOVER (2 + QBATCH_MAX)
-#define CNT_INTS (2 + 2 * QBATCH_MAX)
 
-// every group whose upper bound reaches a query's threshold and that was not rescored yet -> (query, group) pair list.
+// every group whose upper bound reaches a query's threshold and that was not rescored yet -> a candidate: a (query, ROW) pair when the
+// group's second-largest row bound is below the threshold (only the arg-max row can matter), a (query, group) pair otherwise.
 // Thread t of a block owns queries 4t .. 4t+3 (one 16-B load per group row: a wave reads 1 KB of the row, fully coalesced); the block
 // walks `gpb` consecutive groups.
-__global__ __launch_bounds__(256) void collect_pairs_kernel(const float* __restrict__ gmax, int64_t ldg, int64_t n_groups, int nq,
+#define COLLECT_LDS_CAP 1024         // candidates a block buffers per list before it reserves its range of the global list
+__global__ __launch_bounds__(256) void collect_pairs_kernel(const float* __restrict__ gmax, const uint32_t* __restrict__ aux, int64_t ldg,
+                                                             int64_t n_groups, int64_t n_rows, int nq,
                                                              const float* __restrict__ thr, const int32_t* __restrict__ selg, int K,
-                                                             unsigned long long* __restrict__ pairs, int* __restrict__ counters, int gpb) {
+                                                             unsigned long long* __restrict__ pairs, unsigned long long* __restrict__ rpairs,
+                                                             int* __restrict__ counters, int gpb) {
+    // One global atomic per block and list, not one per candidate: ~150 candidates per query x 1 024 queries on ONE counter word is
+    // 1.8 ms of serialised atomics (a word takes ~88 per microsecond; first version of this kernel, profiles/r03).  Candidates go to
+    // two LDS buffers through LDS atomics; the block then reserves its ranges and copies them out.  A buffer that fills up (clustered
+    // data: thousands of candidates in 64 groups) spills straight to the global list.
+    __shared__ unsigned long long lp[COLLECT_LDS_CAP], lr[COLLECT_LDS_CAP];
+    __shared__ int ln[2], lbase[2];
+    if (threadIdx.x < 2) ln[threadIdx.x] = 0;
+    __syncthreads();
     const int q0 = threadIdx.x * 4;
-    if (q0 >= ldg) return;                                        // no barrier in this kernel
-    float t4[4];
+    if (q0 < ldg) {
+        float t4[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) t4[j] = (q0 + j < nq) ? thr[q0 + j] : INFINITY;
-    const int64_t g0 = (int64_t)blockIdx.x * gpb;
-    const int64_t g1 = g0 + gpb < n_groups ? g0 + gpb : n_groups;
-    for (int64_t g = g0; g < g1; ++g) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(gmax + g * ldg + q0);
+        for (int j = 0; j < 4; ++j) t4[j] = (q0 + j < nq) ? thr[q0 + j] : INFINITY;
+        const int64_t g0 = (int64_t)blockIdx.x * gpb;
+        const int64_t g1 = g0 + gpb < n_groups ? g0 + gpb : n_groups;
+        for (int64_t g = g0; g < g1; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(gmax + g * ldg + q0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (!(v[j] >= t4[j])) continue;
-            const int q = q0 + j;
-            bool sel = false;
-            for (int jj = 0; jj < K; ++jj) sel = sel || (selg[q * K + jj] == (int32_t)g);
-            if (sel) continue;
-            const int qc = atomicAdd(&counters[CNT_QCOUNT + q], 1);
-            if (qc < PAIR_CAP_PER_QUERY) {
-                const int p = atomicAdd(&counters[0], 1);
-                pairs[p] = ((unsigned long long)q << 32) | (unsigned long long)(uint32_t)g;
-            } else
-                counters[CNT_QOVER + q] = 1;
+            for (int j = 0; j < 4; ++j) {
+                if (!(v[j] >= t4[j])) continue;
+                const int q = q0 + j;
+                bool sel = false;
+                for (int jj = 0; jj < K; ++jj) sel = sel || (selg[q * K + jj] == (int32_t)g);
+                if (sel) continue;
+                const int qc = atomicAdd(&counters[CNT_QCOUNT + q], 1);
+                if (qc >= PAIR_CAP_PER_QUERY) { counters[CNT_QOVER + q] = 1; continue; }
+                const uint32_t a = aux[g * ldg + q];
+                const int64_t row = g * GROUP_ROWS + (int64_t)(a & 63u);
+                const bool single = __uint_as_float(a & 0xFFFF0000u) < t4[j] && row < n_rows;
+                const unsigned long long e = ((unsigned long long)q << 32) | (unsigned long long)(uint32_t)(single ? row : g);
+                const int slot = atomicAdd(&ln[single ? 1 : 0], 1);
+                if (slot < COLLECT_LDS_CAP) (single ? lr : lp)[slot] = e;
+                else (single ? rpairs : pairs)[atomicAdd(&counters[single ? 1 : 0], 1)] = e;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int n = ln[threadIdx.x] < COLLECT_LDS_CAP ? ln[threadIdx.x] : COLLECT_LDS_CAP;
+        lbase[threadIdx.x] = n ? atomicAdd(&counters[threadIdx.x], n) : 0;
+        ln[threadIdx.x] = n;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ln[0]; i += 256) pairs[lbase[0] + i] = lp[i];
+    for (int i = threadIdx.x; i < ln[1]; i += 256) rpairs[lbase[1] + i] = lr[i];
+}
+
+// eight lanes per (query, row) candidate: the row's exact score (the same exact_row_score as everywhere); at or above the query's
+// threshold it joins the survivor list
+__device__ __forceinline__ void row_candidates(const unsigned long long* __restrict__ rpairs, const int* __restrict__ counters,
+                                               const f16_t* __restrict__ Q, const f16_t* __restrict__ C, int D,
+                                               const float* __restrict__ thr, float* __restrict__ surv_s,
+                                               int64_t* __restrict__ surv_i, int* __restrict__ nsurv) {
+    const int lane = threadIdx.x & 63, l8 = lane & 7, nch = D >> 3;
+    const int np = counters[1];
+    // a wave takes 8 candidates per step (8 lanes each); `base` is wave-uniform, so every lane runs every step (the butterfly inside
+    // exact_row_score needs the whole wave)
+    for (int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; base < np; base += gridDim.x * 32) {
+        const int p0 = base + (lane >> 3);
+        const bool ok = p0 < np;
+        const unsigned long long pr = rpairs[ok ? p0 : 0];
+        const int q = (int)(pr >> 32);
+        const int64_t row = (int64_t)(uint32_t)pr;
+        const bool go = ok && !counters[CNT_QOVER + q];
+        const float a = exact_row_score(C + row * D, Q + (int64_t)q * D, nch, l8, go);
+        if (l8 == 0 && go && a >= thr[q]) {
+            const int sidx = atomicAdd(&nsurv[q], 1);
+            if (sidx < SURV_CAP) { surv_s[q * SURV_CAP + sidx] = a; surv_i[q * SURV_CAP + sidx] = row; }
         }
     }
 }
 
-// one wave per pair: exact scores of the group's 64 rows (the same exact_row_score as everywhere), rows at or above the query's
-// threshold are appended to its survivor list
-__global__ __launch_bounds__(256) void pair_rescore_kernel(const unsigned long long* __restrict__ pairs, const int* __restrict__ counters,
+// Candidate rescoring, one launch: first the (query, row) candidates (see row_candidates), then the (query, group) ones — one wave per
+// pair: exact scores of the group's 64 rows (the same exact_row_score as everywhere); rows at or above the query's threshold are appended
+// to its survivor list.
+__global__ __launch_bounds__(256) void pair_rescore_kernel(const unsigned long long* __restrict__ pairs, const unsigned long long* __restrict__ rpairs,
+                                                            const int* __restrict__ counters,
                                                             const f16_t* __restrict__ Q, const f16_t* __restrict__ C, int64_t n_rows, int D,
                                                             const float* __restrict__ thr, float* __restrict__ surv_s,
                                                             int64_t* __restrict__ surv_i, int* __restrict__ nsurv) {
+    row_candidates(rpairs, counters, Q, C, D, thr, surv_s, surv_i, nsurv);
     const int lane = threadIdx.x & 63, l8 = lane & 7, rsub = lane >> 3, nch = D >> 3;
     const int np = counters[0];
     for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < np; p += gridDim.x * 4) {
@@ -618,7 +840,7 @@ __global__ __launch_bounds__(256) void merge_survivors_kernel(float* __restrict_
     const bool over = n > SURV_CAP || counters[CNT_QOVER + q] != 0;
     if (lane == 0) {
         redo[q] = over ? 1 : 0;
-        if (stats) { if (over) atomicAdd(&stats[0], 1ull); if (q == 0) atomicAdd(&stats[1], (unsigned long long)counters[0]); }
+        if (stats) { if (over) atomicAdd(&stats[0], 1ull); if (q == 0) atomicAdd(&stats[1], (unsigned long long)(counters[0] + counters[1])); }
     }
     if (over) return;
     constexpr int R = SURV_CAP / 64 + 1;
@@ -658,16 +880,13 @@ __global__ __launch_bounds__(256) void merge_kernel(const float* __restrict__ ps
             if (vi < 0) continue;
             if (bslot < 0 || v > bs || (v == bs && vi < bi)) { bs = v; bi = vi; bslot = sl; }
         }
-        float ws = bs; int64_t wi = bi; int wl = bslot >= 0 ? lane : -1;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float os = __shfl_xor(ws, o); const int64_t oi = __shfl_xor(wi, o); const int ol = __shfl_xor(wl, o);
-            if (ol >= 0 && (wl < 0 || os > ws || (os == ws && oi < wi))) { ws = os; wi = oi; wl = ol; }
-        }
-        if (wl == lane && bslot >= 0) taken |= (1ull << bslot);
+        float ws = bslot >= 0 ? bs : -INFINITY; int64_t wi = bslot >= 0 ? bi : INT64_MAX;
+        wave_argbest(ws, wi);
+        const bool found = wi != INT64_MAX;
+        if (found && bslot >= 0 && bi == wi && bs == ws) taken |= (1ull << bslot);      // (global ids are distinct across shards)
         if (lane == 0) {
-            out_s[(int64_t)q * k + r] = wl >= 0 ? ws : -INFINITY;
-            out_i[(int64_t)q * k + r] = wl >= 0 ? wi : -1;
+            out_s[(int64_t)q * k + r] = found ? ws : -INFINITY;
+            out_i[(int64_t)q * k + r] = found ? wi : -1;
         }
     }
 }
@@ -704,7 +923,7 @@ __global__ __launch_bounds__(256) void fill_unit_rows_kernel(f16_t* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct TopkWs { int64_t stats, gmax, part_s, part_g, q8, qmeta, thr, selg, counters, nsurv, redo, pairs, surv_s, surv_i, total;
+struct TopkWs { int64_t stats, gmax, aux, part_s, part_g, q8, qmeta, thr, selg, counters, nsurv, redo, pairs, rpairs, surv_s, surv_i, total;
                 int64_t ldg; int nsplit; int64_t n_groups; };
 static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim) {
     TopkWs w;
@@ -718,6 +937,7 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim) {
     auto take = [&](int64_t b) { int64_t r = o; o += round_up64(b, 256); return r; };
     w.stats = take(16);                                          // certificate counters, at the allocation's start (zeroed per call)
     w.gmax = take(w.n_groups * w.ldg * 4);
+    w.aux = take(w.n_groups * w.ldg * 4);                        // int8 pre-filter: second bound + arg-max row per (query, group)
     w.part_s = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
     w.part_g = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
     w.q8 = take(w.ldg * (int64_t)dim);                           // int8 pre-filter: the query batch quantised (small; always reserved)
@@ -729,6 +949,7 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim) {
     w.nsurv = take(QBATCH_MAX * 4);
     w.redo = take(qc * 4);
     w.pairs = take(qc * PAIR_CAP_PER_QUERY * 8);
+    w.rpairs = take(qc * PAIR_CAP_PER_QUERY * 8);
     w.surv_s = take(qc * SURV_CAP * 4);
     w.surv_i = take(qc * SURV_CAP * 8);
     w.total = o;
@@ -756,15 +977,15 @@ static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_row
 
 template <int BM, bool GLDS>
 static int launch_groupmax_i8(const int8_t* Q8, const float2* qmeta, int nq, const int8_t* C8, const float2* cmeta, int64_t n_rows, int D,
-                              float* gmax, int64_t ldg, hipStream_t st) {
+                              float* gmax, uint32_t* aux, int64_t ldg, hipStream_t st) {
     using ML = GemmMainloop<i8pair_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
     auto kern = search_groupmax_i8_kernel<BM, GLDS>;
-    constexpr int smem_bytes = (BM == 256 && GLDS) ? Gemm8Phase<i8pair_t, 2>::STAGE_OFF : ML::SMEM_BYTES;
+    constexpr int smem_bytes = ((BM == 256 && GLDS) ? Gemm8Phase<i8pair_t, 2>::STAGE_OFF : ML::SMEM_BYTES) + (BM >= 128 ? 4096 : 0);
     ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem_bytes));
     const int tq = cdiv(nq, BM);
     const int64_t tn = (n_rows + 255) / 256;
     ARX_REQUIRE(tq * tn < (1ll << 31), "grid too large");
-    kern<<<(int)(tq * tn), 512, smem_bytes, st>>>(Q8, qmeta, nq, C8, cmeta, n_rows, D, tq, (int)tn, gmax, ldg);
+    kern<<<(int)(tq * tn), 512, smem_bytes, st>>>(Q8, qmeta, nq, C8, cmeta, n_rows, D, tq, (int)tn, gmax, aux, ldg);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -811,7 +1032,7 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
     unsigned long long* stats = (unsigned long long*)(ws + L.stats);
     if (!collect) {
         kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
-                                   debug_drop, stats, nullptr, nullptr, nullptr);
+                                   debug_drop, stats, nullptr, nullptr, nullptr, nullptr, nullptr);
         ARX_HIP_CHECK(hipGetLastError());
         return ARX_OK;
     }
@@ -823,29 +1044,33 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
     int* nsurv = (int*)(ws + L.nsurv);
     int32_t* redo = (int32_t*)(ws + L.redo);
     unsigned long long* pairs = (unsigned long long*)(ws + L.pairs);
+    unsigned long long* rpairs = (unsigned long long*)(ws + L.rpairs);
+    const uint32_t* aux = (const uint32_t*)(ws + L.aux);
     float* surv_s = (float*)(ws + L.surv_s);
     int64_t* surv_i = (int64_t*)(ws + L.surv_i);
-    ARX_HIP_CHECK(hipMemsetAsync(ws + L.counters, 0, (size_t)(L.nsurv - L.counters) + QBATCH_MAX * 4, st));
     kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
-                               debug_drop, nullptr, thr, selg, nullptr);
+                               debug_drop, nullptr, thr, selg, nullptr, counters, nsurv);
     ARX_HIP_CHECK(hipGetLastError());
     {
         const int gpb = 64;                                          // groups per block: 64 x ldg x 4 B = 16-256 KB of gmax per block
-        collect_pairs_kernel<<<(int)((L.n_groups + gpb - 1) / gpb), 256, 0, st>>>(gmax, L.ldg, L.n_groups, nq, thr, selg, K, pairs, counters, gpb);
+        collect_pairs_kernel<<<(int)((L.n_groups + gpb - 1) / gpb), 256, 0, st>>>(gmax, aux, L.ldg, L.n_groups, n_rows, nq, thr, selg, K, pairs, rpairs,
+                                                                                  counters, gpb);
     }
     ARX_HIP_CHECK(hipGetLastError());
-    pair_rescore_kernel<<<2048, 256, 0, st>>>(pairs, counters, Q, C, n_rows, D, thr, surv_s, surv_i, nsurv);
+    pair_rescore_kernel<<<2048, 256, 0, st>>>(pairs, rpairs, counters, Q, C, n_rows, D, thr, surv_s, surv_i, nsurv);
     ARX_HIP_CHECK(hipGetLastError());
     merge_survivors_kernel<<<cdiv(nq, 4), 256, 0, st>>>(out_s, out_i, nq, k, idx_base, surv_s, surv_i, nsurv, counters, redo, stats);
     ARX_HIP_CHECK(hipGetLastError());
     kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
-                               debug_drop, stats, nullptr, nullptr, redo);
+                               debug_drop, nullptr, nullptr, nullptr, redo, nullptr, nullptr);      // (merge_survivors already counted these queries)
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
 
-// query batches of more than this take the fp16 pass even when an int8 index is given (tuning knob; see the measurement in DESIGN.md)
-#define I8_MAX_NQ_DEFAULT 128
+// query batches of more than this take the fp16 pass even when an int8 index is given (tuning knob).  Default = every batch size: with
+// single-row candidates (aux word) and block-aggregated candidate lists the int8 pass wins at every Qb measured (10 M x 768, same box:
+// 1.67x at Qb = 1, 1.45x at 64, 1.31x at 256, 1.40x at 1 024: profiles/r03); round 2's crossover was 128.
+#define I8_MAX_NQ_DEFAULT QBATCH_MAX
 static int g_i8_max_nq = I8_MAX_NQ_DEFAULT;
 extern "C" int32_t arx_topk_set_i8_max_queries(int32_t n) {
     g_i8_max_nq = n < 0 ? I8_MAX_NQ_DEFAULT : n;
@@ -867,6 +1092,7 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
                             int64_t ws_bytes, void* stream) {
     ARX_REQUIRE(corpus && queries && out_scores && out_ids && ws, "null pointer argument");
     ARX_REQUIRE(!index_i8 || (dim % 128 == 0 && dim <= 1024), "int8 pre-filter: dim=%d must be a multiple of 128, <= 1024", dim);
+    ARX_REQUIRE(!index_i8 || n_rows < (1ll << 32), "int8 pre-filter: row candidates are 32-bit");
     ARX_REQUIRE(n_rows > 0 && n_queries > 0, "empty corpus or query set");
     ARX_REQUIRE(dim > 0 && dim % 64 == 0 && dim <= 8192, "dim=%d must be a multiple of 64", dim);
     ARX_REQUIRE(k > 0 && k <= KMAX, "k=%d out of range 1..%d", k, KMAX);
@@ -896,9 +1122,10 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
             const int8_t* C8 = (const int8_t*)index_i8;
             const float2* cmeta = (const float2*)((const char*)index_i8 + i8_meta_offset(n_rows, dim));
             ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
-            rc = nq <= 64 ? launch_groupmax_i8<64, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, L.ldg, st)
-               : nq <= 128 ? launch_groupmax_i8<128, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, L.ldg, st)
-                           : launch_groupmax_i8<256, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, L.ldg, st);
+            uint32_t* aux = (uint32_t*)((char*)ws + L.aux);
+            rc = nq <= 64 ? launch_groupmax_i8<64, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
+               : nq <= 128 ? launch_groupmax_i8<128, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
+                           : launch_groupmax_i8<256, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st);
         } else {
         ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
 #ifdef ARX_DEV_VARIANTS

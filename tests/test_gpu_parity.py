@@ -222,6 +222,12 @@ def test_search_int8_prefilter_adversarial_rows(hip):
         idx = ShardIndex(torch.from_numpy(Cm).cuda(), prefilter="int8")
         s, i = idx.search(torch.from_numpy(Q).cuda(), k)
         _assert_topk_valid(Cm, Q, s.cpu().numpy(), i.cpu().numpy(), k, tol=2e-6 * float(np.abs(Cm.astype(np.float32)).max()) ** 2 * 4)
+    # the same rows under the wide query tiles (Qb = 256 and > 1024: the int8 pass is now the default at every batch size)
+    for nq_big in (256, 1100):
+        Qb = np.concatenate([Q, SO.unit_rows_f16(nq_big - len(Q), d, 33)])
+        idx = ShardIndex(torch.from_numpy(Cm).cuda(), prefilter="int8")
+        s, i = idx.search(torch.from_numpy(Qb).cuda(), 10)
+        _assert_topk_valid(Cm, Qb, s.cpu().numpy(), i.cpu().numpy(), 10, tol=2e-6 * float(np.abs(Cm.astype(np.float32)).max()) ** 2 * 4)
     Cn, Qn, planted = _near_tied_corpus(60)
     idx = ShardIndex(torch.from_numpy(Cn).cuda(), idx_base=7, prefilter="int8")
     s, i = idx.search(torch.from_numpy(Qn).cuda(), 10)
@@ -250,6 +256,18 @@ def test_search_int8_prefilter_overflow_falls_back_to_the_exhaustive_kernel(hip)
     s, i = idx.search(torch.from_numpy(Qr).cuda(), 10)
     _assert_topk_valid(Cr, Qr, s.cpu().numpy(), i.cpu().numpy(), 10, idx_base=50)
     assert idx.certificate_stats()[0] >= 1
+    # the same with 256 and 1 030 queries per call (wide query tiles, two internal passes): overflow stays per query
+    for nq_big in (256, 1030):
+        Qb = np.concatenate([Qr, SO.unit_rows_f16(nq_big - len(Qr), 256, 12)])
+        s, i = idx.search(torch.from_numpy(Qb).cuda(), 10)
+        _assert_topk_valid(Cr, Qb, s.cpu().numpy(), i.cpu().numpy(), 10, idx_base=50)
+        flagged, _ = idx.certificate_stats()
+        assert 1 <= flagged <= 3, flagged
+    # every query of a 300-query batch overflowing: all go through the exhaustive kernel, all exact
+    Q300 = SO.unit_rows_f16(300, 128, 2)
+    idx = ShardIndex(torch.from_numpy(Cm).cuda(), prefilter="int8")
+    s, i = idx.search(torch.from_numpy(Q300).cuda(), 10)
+    assert np.array_equal(i.cpu().numpy(), np.tile(np.arange(10), (300, 1))) and idx.certificate_stats()[0] == 300
 
 
 def test_search_duplicate_rows_everywhere(hip):
