@@ -329,8 +329,12 @@ __device__ __forceinline__ void topk_insert(float (&s)[K], int64_t (&id)[K], flo
 template <int K>
 __global__ __launch_bounds__(256) void select_groups_kernel(const float* __restrict__ gmax, int64_t ldg, int64_t n_groups,
                                                              int64_t n_real, int nq, int nsplit,
-                                                             float* __restrict__ part_s, int32_t* __restrict__ part_g) {
+                                                             float* __restrict__ part_s, int32_t* __restrict__ part_g,
+                                                             unsigned long long* __restrict__ zero_stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // the certificate counters of this search call start at zero (first internal pass only; the rescore kernels that add to them run
+    // after this one on the stream): saves a 16-byte memset node per call, which a 0.25-ms small-shard search can see
+    if (zero_stats && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 2) zero_stats[threadIdx.x] = 0ull;
     float* ls = reinterpret_cast<float*>(smem);                     // [4][K][64]
     int32_t* lg = reinterpret_cast<int32_t*>(smem + 4 * K * 64 * 4);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -442,32 +446,34 @@ __device__ __forceinline__ void wave_topk(float (&s)[R], int64_t (&id)[R], int k
 // in this file: pass B2 and the certificate's fallback both rank by it.
 __device__ __forceinline__ float exact_row_score(const f16_t* __restrict__ crow, const f16_t* qs, int nch, int l8, bool ok) {
     float a0 = 0.f, a1 = 0.f;
+    // chunks l8, l8 + 8, ... in ascending order, whatever the batching below: the sum's order (hence its bits) is fixed; the batches
+    // only decide how many of the row's 16-B loads are in flight at once (six: a 768-d row is two dependent round trips instead of three)
+    auto fma8 = [&](const f16x8& cv, const f16x8& qq) {
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            a0 = fmaf((float)cv[e], (float)qq[e], a0);
+            a1 = fmaf((float)cv[e + 1], (float)qq[e + 1], a1);
+        }
+    };
     if (ok) {
         int ch = l8;
 #pragma unroll 1
-        for (; ch + 24 < nch; ch += 32) {
-            f16x8 cv[4], qq[4];
+        for (; ch + 40 < nch; ch += 48) {
+            f16x8 cv[6];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) cv[u] = *reinterpret_cast<const f16x8*>(crow + (ch + 8 * u) * 8);
+            for (int u = 0; u < 6; ++u) cv[u] = *reinterpret_cast<const f16x8*>(crow + (ch + 8 * u) * 8);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) qq[u] = *reinterpret_cast<const f16x8*>(qs + (ch + 8 * u) * 8);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    a0 = fmaf((float)cv[u][e], (float)qq[u][e], a0);
-                    a1 = fmaf((float)cv[u][e + 1], (float)qq[u][e + 1], a1);
-                }
+            for (int u = 0; u < 6; ++u) fma8(cv[u], *reinterpret_cast<const f16x8*>(qs + (ch + 8 * u) * 8));
         }
-        for (; ch < nch; ch += 8) {
-            const f16x8 cv = *reinterpret_cast<const f16x8*>(crow + ch * 8);
-            const f16x8 qq = *reinterpret_cast<const f16x8*>(qs + ch * 8);
+#pragma unroll 1
+        for (; ch + 8 < nch; ch += 16) {
+            f16x8 cv[2];
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                a0 = fmaf((float)cv[e], (float)qq[e], a0);
-                a1 = fmaf((float)cv[e + 1], (float)qq[e + 1], a1);
-            }
+            for (int u = 0; u < 2; ++u) cv[u] = *reinterpret_cast<const f16x8*>(crow + (ch + 8 * u) * 8);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) fma8(cv[u], *reinterpret_cast<const f16x8*>(qs + (ch + 8 * u) * 8));
         }
+        for (; ch < nch; ch += 8) fma8(*reinterpret_cast<const f16x8*>(crow + ch * 8), *reinterpret_cast<const f16x8*>(qs + ch * 8));
     }
     float a = a0 + a1;
     a += __shfl_xor(a, 4); a += __shfl_xor(a, 2); a += __shfl_xor(a, 1);
@@ -584,21 +590,17 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
         if (lane == 0) { sh_u = u; sh_qn = sqrtf(qq); }
     }
     __syncthreads();
-    // (3) exact scores: 8 lanes per corpus row, 8 rows per step, several independent 16-B loads in flight per lane
+    // (3) exact scores: 8 lanes per corpus row, 8 rows per wave and step; the K x 64 rows are dealt to ALL the block's waves (a 16-wave
+    // block scores its 768 rows in 6 steps; one group per wave left four waves idle for 8)
     const int nch = D >> 3, l8 = lane & 7, rsub = lane >> 3;
-    constexpr int GPW = (K + NW - 1) / NW;                    // groups per wave
-#pragma unroll
-    for (int gq = 0; gq < GPW; ++gq) {
-        const int gidx = w + gq * NW;
-        if (gidx >= K) continue;
+    constexpr int GPW = (K + NW - 1) / NW;                    // groups per wave in the per-wave top-k below
+    for (int t0 = w * 8; t0 < K * GROUP_ROWS; t0 += NW * 8) {
+        const int t = t0 + rsub, gidx = t >> 6, rr = t & 63;
         const int gsel = sel_g[gidx];
-        for (int r8 = 0; r8 < GROUP_ROWS; r8 += 8) {
-            const int rr = r8 + rsub;
-            const int64_t row = (int64_t)gsel * GROUP_ROWS + rr;
-            const bool ok = gsel >= 0 && row < n_rows;
-            const float a = exact_row_score(C + row * D, qs, nch, l8, ok);
-            if (l8 == 0) { gs[gidx * GROUP_ROWS + rr] = ok ? a : -INFINITY; gi_[gidx * GROUP_ROWS + rr] = ok ? row : -1; }
-        }
+        const int64_t row = (int64_t)gsel * GROUP_ROWS + rr;
+        const bool ok = gsel >= 0 && row < n_rows;
+        const float a = exact_row_score(C + row * D, qs, nch, l8, ok);
+        if (l8 == 0) { gs[t] = ok ? a : -INFINITY; gi_[t] = ok ? row : -1; }
     }
     __syncthreads();
     // each wave: top-k of the rows of its groups (read back one row per lane)
@@ -931,7 +933,8 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim) {
     w.ldg = round_up64(qb, 64);
     w.n_groups = (n_rows + GROUP_ROWS - 1) / GROUP_ROWS;
     const int64_t n_super = (w.n_groups + SUPER - 1) / SUPER;
-    int64_t ns = (n_super + 4 * 8 - 1) / (4 * 8);               // ~8 super-groups per wave-slice
+    int64_t ns = (n_super + 4 * 2 - 1) / (4 * 2);               // ~2 super-groups per wave-slice (each is one dependent round of 16 loads: a 625 k-row
+                                                                 // shard spent 21 us in eight such rounds per wave; capped at 256 slices = rescore's merge width)
     w.nsplit = (int)(ns < 1 ? 1 : (ns > 256 ? 256 : ns));
     int64_t o = 0;
     auto take = [&](int64_t b) { int64_t r = o; o += round_up64(b, 256); return r; };
@@ -1011,7 +1014,7 @@ extern "C" int32_t arx_topk_build_i8(const void* corpus, int64_t n_rows, int32_t
 template <int K, int NT>
 static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D,
                               int k, float* out_s, int64_t* out_i, int64_t idx_base, float tau_scale, int debug_drop, hipStream_t st,
-                              bool collect = false) {
+                              bool collect, bool first_pass) {
     float* gmax = (float*)(ws + L.gmax);
     float* ps = (float*)(ws + L.part_s);
     int32_t* pg = (int32_t*)(ws + L.part_g);
@@ -1021,7 +1024,8 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
         auto ksel = select_groups_kernel<K>;
         if (smem_sel > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)ksel, smem_sel));
         ProfScope psc(ARX_K_SEARCH_SELECT, st);
-        ksel<<<grid, 256, smem_sel, st>>>(gmax, L.ldg, (L.n_groups + SUPER - 1) / SUPER, L.n_groups, nq, L.nsplit, ps, pg);
+        ksel<<<grid, 256, smem_sel, st>>>(gmax, L.ldg, (L.n_groups + SUPER - 1) / SUPER, L.n_groups, nq, L.nsplit, ps, pg,
+                                          first_pass ? (unsigned long long*)(ws + L.stats) : nullptr);
         ARX_HIP_CHECK(hipGetLastError());
     }
     const int nslices = L.nsplit;
@@ -1107,7 +1111,6 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
     // certificate tolerance (rescore_kernel step 5): eps_A + eps_B per unit of |q|_2, corpus rows of norm <= 1 + 2^-9
     const float tau_scale = (0.3125f * (float)dim + 4.0f) * 5.9604645e-8f * (1.0f + 1.0f / 512.0f) * g_dbg_tau_mult;   // arx_topk_set_debug: >= 1
     const int debug_drop = g_dbg_drop;
-    ARX_HIP_CHECK(hipMemsetAsync((char*)ws + L.stats, 0, 16, st));
     for (int q0 = 0; q0 < n_queries; q0 += QBATCH_MAX) {
         const int nq = (n_queries - q0) < QBATCH_MAX ? (n_queries - q0) : QBATCH_MAX;
         const f16_t* Q = (const f16_t*)queries + (int64_t)q0 * dim;
@@ -1144,9 +1147,9 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         int64_t* oi = out_ids + (int64_t)q0 * k;
         // rescore geometry (same-box A/B, r02): a 16-wave block per query is fastest while the blocks fit the chip at once
         // (0.10 vs 0.13 ms at <= 64 queries); 4-wave blocks, eight to a CU, when there are thousands (2.9 vs 5.4 ms per 10 k)
-        if (k > 10) rc = run_select_rescore<KSEL_BIG, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8);
-        else if (nq <= 128) rc = run_select_rescore<KSEL_SMALL, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8);
-        else rc = run_select_rescore<KSEL_SMALL, 256>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8);
+        if (k > 10) rc = run_select_rescore<KSEL_BIG, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
+        else if (nq <= 128) rc = run_select_rescore<KSEL_SMALL, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
+        else rc = run_select_rescore<KSEL_SMALL, 256>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
         if (rc != ARX_OK) return rc;
     }
     return ARX_OK;

@@ -57,6 +57,37 @@ class ShardIndex:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.corpus.device)
         return self._ws
 
+    def search_many(self, batches, k: int = 10, distributed: bool = False, group=None):
+        """A STREAM of query batches, two in flight: batch b + 1's scan of the shard (pass A: every CU, HBM-bound) runs while batch b's
+        select / rescore / certificate tail (a few dozen blocks, latency-bound) and — under a process group — its all-gather of the
+        [Q, k] partials and the merge finish (SURVEY.md §8e "Overlap": on a 625 k-row shard the tail and the exchange are as long as the
+        pass itself).  Two side streams, each with its own workspace; the caller's stream waits for both before this returns.
+        Same results as calling `search` / `search_distributed` batch by batch."""
+        import torch.distributed as dist
+        dev = self.corpus.device
+        cur = torch.cuda.current_stream(dev)
+        if not hasattr(self, "_lanes"):
+            self._lanes = [(torch.cuda.Stream(dev), None), (torch.cuda.Stream(dev), None)]
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        out = []
+        keep_ws = self._ws
+        for b, q in enumerate(batches):
+            st, ws = self._lanes[b & 1]
+            st.wait_event(ready)
+            with torch.cuda.stream(st):
+                self._ws = ws
+                s, i = self.search(q, k)
+                self._lanes[b & 1] = (st, self._ws)
+                if distributed and dist.is_initialized():
+                    s, i = merge_partials(*gather_partials(s, i, group), k)
+                q.record_stream(st); s.record_stream(cur); i.record_stream(cur)
+            out.append((s, i))
+        self._ws = keep_ws
+        for st, _ in self._lanes:
+            cur.wait_stream(st)
+        return out
+
     def search(self, queries_f16: torch.Tensor, k: int = 10) -> Tuple[torch.Tensor, torch.Tensor]:
         """queries fp16 [Q, D] (device) -> (scores f32 [Q, k], ids int64 [Q, k]); ids are global
         (local row + idx_base); score desc, ties -> lower id; (-inf, -1) pads when k > n_rows."""

@@ -432,7 +432,7 @@ def main():
             tm = torch.tensor([x], dtype=torch.float64, device=dev); dist.all_reduce(tm, op=dist.ReduceOp.MAX); return float(tm.item())
         return x
 
-    def time_search(ix, queries, qb, n_rows, D, int8_bytes=False):
+    def time_search(ix, queries, qb, n_rows, D, int8_bytes=False, pipelined=False):
         """QPS of `ix.search_distributed` (local top-k [+ all-gather + merge under a process group]) on batches of qb queries, and the
         per-kernel split of the same calls (library events on the launch stream)."""
         nq_all = queries.shape[0]
@@ -457,6 +457,17 @@ def main():
              "select_ms": round(p["search_select"][0] / reps, 3), "rescore_ms": round(p["search_rescore"][0] / reps, 3)}
         if int8_bytes:
             e["passA_bytes_per_launch"] = pass_bytes
+        if pipelined:
+            # the same batches as a STREAM, two in flight (ShardIndex.search_many): batch b + 1's pass A under batch b's select / rescore
+            # tail and exchange
+            nb = max(8, reps)
+            qs_ = [queries[((r * qb) % max(1, nq_all - qb + 1)):((r * qb) % max(1, nq_all - qb + 1)) + qb] for r in range(nb)]
+            ix.search_many(qs_[:2], 10, distributed=use_dist)
+            barrier(); t0 = time.perf_counter()
+            ix.search_many(qs_, 10, distributed=use_dist)
+            barrier(); dtp = allmax(time.perf_counter() - t0)
+            e["qps_pipelined"] = round(nb * qb / dtp, 1)
+            e["ms_per_batch_pipelined"] = round(dtp / nb * 1e3, 3)
         return e
 
     search = None
@@ -545,7 +556,7 @@ def main():
         strong = {}
         for qb in (64, 256, nq_all):
             qb = min(qb, nq_all)
-            e = time_search(sidx, queries, qb, hi - lo, D)
+            e = time_search(sidx, queries, qb, hi - lo, D, pipelined=qb < nq_all)
             e["passA_ms_at_hbm_roofline"] = round((hi - lo) * D * 2 / HBM_PEAK * 1e3, 4)
             # the exchange step alone: all-gather of [qb, 10] scores + ids and the merge kernel
             ps_, pi_ = sidx.search(queries[:qb], 10)
@@ -582,9 +593,11 @@ def main():
             r625 = {}
             for qb in (64, 256, nq_all):
                 qb = min(qb, nq_all)
-                e = time_search(sl, queries, qb, h8 - l8, D)
+                e = time_search(sl, queries, qb, h8 - l8, D, pipelined=qb < nq_all)
                 e["passA_ms_at_hbm_roofline"] = round((h8 - l8) * D * 2 / HBM_PEAK * 1e3, 4)
                 e["batch_frac_of_hbm_roofline"] = round(((h8 - l8) * D * 2 / HBM_PEAK * 1e3) * max(1, (qb + 1023) // 1024) / e["ms_per_batch"], 4)
+                if "ms_per_batch_pipelined" in e:
+                    e["batch_frac_of_hbm_roofline_pipelined"] = round(((h8 - l8) * D * 2 / HBM_PEAK * 1e3) / e["ms_per_batch_pipelined"], 4)
                 r625[f"Qb={qb}"] = e
             search["shard_625k"] = {"workload": f"rows [{l8}, {h8}) of the configs[3] corpus = one rank's slice of an 8-way cut, {D}-d, on one GPU",
                                     "results": r625}

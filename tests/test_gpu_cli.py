@@ -169,6 +169,10 @@ def test_search_distributed_single_rank_nccl(nccl_world1):
     assert torch.equal(i0, i1) and torch.equal(s0, s1)
     rs, ri = SO.topk_search(Cm, Q, 10)
     assert np.array_equal(i1.cpu().numpy() - 7, ri)
+    # the pipelined form (two batches in flight, all-gather + merge on the side streams)
+    qd = torch.from_numpy(Q).cuda()
+    got = idx.search_many([qd[:16], qd[16:32], qd[32:]], 10, distributed=True)
+    assert torch.equal(torch.cat([i for _, i in got]), i1) and torch.equal(torch.cat([s for s, _ in got]), s1)
 
 
 def test_sharded_branch_single_rank_nccl(nccl_world1, tmp_path, monkeypatch):

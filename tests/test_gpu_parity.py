@@ -384,6 +384,27 @@ def test_sharded_search_equals_global(hip):
     assert (mi.cpu().numpy() == ri).all(axis=1).mean() > 0.95
 
 
+def test_search_many_two_batches_in_flight_equals_batch_by_batch(hip):
+    """`ShardIndex.search_many`: a stream of query batches on two side streams (batch b + 1's pass A under batch b's select / rescore
+    tail) returns exactly what `search` returns batch by batch — fp16 and int8 first passes, ragged last batch, results usable on the
+    caller's stream right away."""
+    from arxiv_rag_amd.index import ShardIndex
+    Cm = SO.unit_rows_f16(64 * 700 + 13, 256, 5); Q = SO.unit_rows_f16(9 * 64 + 17, 256, 6)
+    qd = torch.from_numpy(Q).cuda()
+    batches = [qd[a:a + 64] for a in range(0, len(Q), 64)]
+    for pre in (None, "int8"):
+        idx = ShardIndex(torch.from_numpy(Cm).cuda(), idx_base=100, prefilter=pre)
+        want = [idx.search(b, 10) for b in batches]
+        for _ in range(2):                                                     # second round: the lanes' workspaces are reused
+            got = idx.search_many(batches, 10)
+            tot = sum(float(s.sum()) for s, _ in got)                          # consumed on the caller's stream, no explicit sync
+            assert np.isfinite(tot)
+            for (s, i), (ws_, wi_) in zip(got, want):
+                assert torch.equal(i, wi_) and torch.equal(s, ws_)
+    rs, ri = SO.topk_search(Cm, Q, 10, idx_base=100)
+    assert (torch.cat([i for _, i in got]).cpu().numpy() == ri).all(axis=1).mean() > 0.95
+
+
 def test_merge_kernel_exact(hip):
     from arxiv_rag_amd.index import merge_partials
     rs = np.random.RandomState(0)
