@@ -399,12 +399,30 @@ __device__ __forceinline__ float gelu_fast(float v) {
 }
 
 // Packed erf-GELU, two elements per instruction (v_pk_mul/fma_f32; no transcendental-unit ops, which run at quarter rate):
-// erf(t) ~ t * Q(t^2) on |t| <= 3 (Q of degree 8, least-squares fit on Chebyshev nodes; |erf error| <= 2.8e-5 evaluated in fp32,
-// and 1 - erf(3) = 2.2e-5), clamped beyond.  |GELU error| <= 5.8e-5 absolute — 1/30 of a bf16 ulp at |v| ~ 1 — for about 32
-// VALU cycles per element against ~80 for gelu_fast (12 plain ops + v_rcp + v_exp).
+// erf(t) ~ t * Q(t^2) on |t| <= T, clamped beyond.  Round 2: Q of degree 8 on |t| <= 3 (least-squares fit on Chebyshev nodes;
+// |GELU error| <= 5.8e-5 absolute), about 32 VALU cycles per element against ~80 for gelu_fast (12 plain ops + v_rcp + v_exp).
+// The FFN-1 epilogue is VALU-bound on exactly these instructions (15 per element pair, both waves of a SIMD in it at once), so round 3
+// takes two Horner steps out: degree 6 on |t| <= 2.8 (below).  The output is rounded to bf16 (half-ulp 2e-3 relative) right after.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef ARX_GELU_DEG
+#define ARX_GELU_DEG 6          // round 3 (same-box A/B, profiles/r03/gelu_deg_ab.txt): FFN-1 1.300 -> 1.268 ms, parity margins unchanged; 8 = the round-2 form
+#endif
 __device__ __forceinline__ f32x2 gelu_poly_pk(f32x2 v) {
     f32x2 t = v * 0.70710678118654752f;
+#if ARX_GELU_DEG == 6
+    // Q of degree 6 on |t| <= 2.8 with t Q(t^2) = 1 exactly at the clamp (the saturated branch is exact): |GELU error| <= 1.7e-4
+    // absolute (weighted minimax fit of 0.5 |v| |erf error|; the floor of ANY clamp at 2.8 is 0.5 * 3.96 * (1 - erf 2.8) = 1.5e-4),
+    // two Horner steps fewer than the degree-8 form
+    t.x = __builtin_amdgcn_fmed3f(t.x, -2.8f, 2.8f);
+    t.y = __builtin_amdgcn_fmed3f(t.y, -2.8f, 2.8f);
+    const f32x2 u = t * t;
+    f32x2 q = u * 4.355317931e-06f + -1.504790554e-04f;
+    q = q * u + 2.226357740e-03f;
+    q = q * u + -1.868393674e-02f;
+    q = q * u + 9.987160573e-02f;
+    q = q * u + -3.659436702e-01f;
+    q = q * u + 1.125613580e+00f;
+#else
     t.x = __builtin_amdgcn_fmed3f(t.x, -3.0f, 3.0f);
     t.y = __builtin_amdgcn_fmed3f(t.y, -3.0f, 3.0f);
     const f32x2 u = t * t;
@@ -416,6 +434,7 @@ __device__ __forceinline__ f32x2 gelu_poly_pk(f32x2 v) {
     q = q * u + 1.111308783e-01f;
     q = q * u + -3.753655851e-01f;
     q = q * u + 1.128284454e+00f;
+#endif
     const f32x2 hv = v * 0.5f;
     return (hv * t) * q + hv;                                  // 0.5 v (1 + erf(v / sqrt 2))
 }

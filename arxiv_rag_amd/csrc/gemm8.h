@@ -257,31 +257,25 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
 // through the tile boundary: the seven free issue slots of a tile's last two k-tiles carry the first seven half-tiles of the
 // next tile (exactly what the per-tile prologue above issues), so the first-load latency (~4 us) is paid once per CU instead of
 // once per tile, and the three half-tiles in flight land under the epilogue.  Needs an even number of k-tiles (buffer parity).
-template <int MODE, int KROT = 0>
-__global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_t* __restrict__ A, int64_t lda,
-                                                                      const bf16_t* __restrict__ W, int64_t ldw,
-                                                                      int M, int N, int K, int tiles_m, int tiles_n, EpiParams ep) {
-    using ML = Gemm8Phase<bf16_t, KROT>;
+//
+// The loop is generic over the element type (bf16 / f16 / int8 pairs: Mfma<T>) and over a POLICY object that supplies
+//   bool tile(int o, int& m0, int& n0, int& ko)        block-order index o -> tile origin (false: past the end)
+//   void stage_issue(int m0, int n0, char* stage, int wid, int lane)   per-tile epilogue vectors -> LDS stage (may be a no-op)
+//   void epilogue(acc, m0, n0, wr, wc, lane, stage)     the tile's output
+//   REBASE_W   the W operand is addressed relative to the tile's first row through a per-tile buffer descriptor (a 15-GB corpus does
+//              not fit the 32-bit offsets the encoder's weights use)
+// The encoder's linear layers (EncoderTilePolicy below) and the search's pass A at >= 256 queries (search.hip) share it.
+template <typename T, typename Pol>
+__device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, int64_t lda, const T* __restrict__ W, int64_t ldw,
+                                                      int M, int N, int K, const Pol& pol, char* smem) {
+    using ML = Gemm8Phase<T, 0>;
     using vec = typename ML::vec;
     constexpr int HALF_BYTES = ML::HALF_BYTES, BUF_BYTES = ML::BUF_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: SGPRs
     const int wr = wid >> 2, wc = wid & 3;
     const uint16_t* Ag = reinterpret_cast<const uint16_t*>(A);
     const uint16_t* Wg = reinterpret_cast<const uint16_t*>(W);
-    const int ntiles = tiles_m * tiles_n, stride = gridDim.x, nk = K >> 6;
-
-#ifdef ARX_DEV_VARIANTS
-    const TileWalk walk(tiles_m, tiles_n, K, ep.dev_bw);
-#else
-    const TileWalk walk(tiles_m, tiles_n, K);
-#endif
-    auto tile_of = [&](int o, int& m0, int& n0, int& ko) {
-        int tm = 0, tn = 0;
-        const bool ok = walk.coords(o, tm, tn);
-        m0 = tm * 256; n0 = tn * 256; ko = (tn * KROT) % nk;
-        return ok;
-    };
+    const int stride = gridDim.x, nk = K >> 6;
     auto kcol = [&](int kt, int ko) { int k = kt + ko; return (k >= nk ? k - nk : k) << 6; };
 
     uint32_t aoff[2][2], boff[2][2];
@@ -300,12 +294,16 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             const int cid = it * 512 + tid, r = cid >> 3, c = (cid & 7) ^ ((r >> 1) & 7);
             int gn = n0 + (r >> 5) * 64 + g * 32 + (r & 31);
             gn = gn < N ? gn : N - 1;
+            if constexpr (Pol::REBASE_W) gn -= n0;                          // relative to the tile's descriptor base
             boff[g][it] = ((uint32_t)gn * (uint32_t)ldw + c * 8) * 2u;
         }
     };
     char* const wave_dst = smem + wid * 1024;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)Ag, 0, 0xffffffff, 0x00020000);      // see Gemm8Phase::run
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, 0xffffffff, 0x00020000);
+    auto w_rsrc = [&](int n0) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(Wg + (Pol::REBASE_W ? (int64_t)n0 * ldw : (int64_t)0)), 0, 0xffffffff, 0x00020000);
+    };
+    __amdgpu_buffer_rsrc_t rsW = w_rsrc(0);
     auto issue_a = [&](int h, int kc, int buf) {
         char* dst = wave_dst + buf * BUF_BYTES + h * HALF_BYTES;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)dst, 16, aoff[h][0], kc * 2, 0, 0);
@@ -346,16 +344,17 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[g * 2 + j][h * 4 + i] = Mfma<bf16_t>::mma(wf[j][ks], af[i][ks], acc[g * 2 + j][h * 4 + i]);
+                    acc[g * 2 + j][h * 4 + i] = Mfma<T>::mma(wf[j][ks], af[i][ks], acc[g * 2 + j][h * 4 + i]);
         __builtin_amdgcn_s_setprio(0);
     };
 
     int orig = blockIdx.x;
     int m0, n0, ko;
-    if (!tile_of(orig, m0, n0, ko)) return;
+    if (!pol.tile(orig, m0, n0, ko)) return;
+    if constexpr (Pol::REBASE_W) rsW = w_rsrc(n0);
     set_aoff(0, m0); set_aoff(1, m0); set_boff(0, n0); set_boff(1, n0);
     int sbuf = 0;                                                // epilogue-vector stage of the current tile (alternates)
-    epi_stage_issue<MODE>(ep, m0, n0, smem + ML::STAGE_OFF, wid, lane, N);
+    pol.stage_issue(m0, n0, smem + ML::STAGE_OFF, wid, lane);
     issue_b(0, kcol(0, ko), 0); issue_a(0, kcol(0, ko), 0); issue_b(1, kcol(0, ko), 0); issue_a(1, kcol(0, ko), 0);
     issue_b(0, kcol(1, ko), 1); issue_a(0, kcol(1, ko), 1); issue_b(1, kcol(1, ko), 1);
     wait_vmcnt<6>();
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
     for (;;) {
         const int onext = orig + stride;
         int m0n = 0, n0n = 0, kon = 0;
-        const bool has_next = tile_of(onext, m0n, n0n, kon);
+        const bool has_next = pol.tile(onext, m0n, n0n, kon);
         // interior -> interior tile steps move every source offset by a block-uniform amount
         const bool edge = (m0 + 256 > M) || (m0n + 256 > M);
         const bool nclamp = (n0 + 256 > N) || (n0n + 256 > N);
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             __builtin_amdgcn_sched_barrier(0);
             read_a(cur, 0);
             if (kt == nk - 1 && has_next)                        // next tile's epilogue vectors: ahead of (older than) its A1 pieces
-                epi_stage_issue<MODE>(ep, m0n, n0n, smem + ML::STAGE_OFF + (sbuf ^ 1) * EpiStage::BYTES, wid, lane, N);
+                pol.stage_issue(m0n, n0n, smem + ML::STAGE_OFF + (sbuf ^ 1) * EpiStage::BYTES, wid, lane);
             if (!more1 && has_next) {                            // the stream's A1 pieces now come from the next tile
                 if (edge) { asm volatile("" : "+s"(m0n)); set_aoff(1, m0n); }      // clamped rows: recompute (last tile row only)
                 else { aoff[1][0] += d_a; aoff[1][1] += d_a; }
@@ -404,8 +403,13 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
             // ---- phase 2
             read_b(cur, 1, wf1);
             if (kt == nk - 2 && has_next) {
-                if (nclamp) { asm volatile("" : "+s"(n0n)); set_boff(0, n0n); set_boff(1, n0n); }   // half-present last n-tile: clamped rows
-                else { boff[0][0] += d_b; boff[0][1] += d_b; boff[1][0] += d_b; boff[1][1] += d_b; }
+                if constexpr (Pol::REBASE_W) {                   // every B piece from here on belongs to the next tile: its own descriptor
+                    rsW = w_rsrc(n0n);
+                    if (nclamp) { asm volatile("" : "+s"(n0n)); set_boff(0, n0n); set_boff(1, n0n); }
+                } else {
+                    if (nclamp) { asm volatile("" : "+s"(n0n)); set_boff(0, n0n); set_boff(1, n0n); }   // half-present last n-tile: clamped rows
+                    else { boff[0][0] += d_b; boff[0][1] += d_b; boff[1][0] += d_b; boff[1][1] += d_b; }
+                }
                 if (edge) { asm volatile("" : "+s"(m0n)); set_aoff(0, m0n); }
                 else { aoff[0][0] += d_a; aoff[0][1] += d_a; }
             }
@@ -435,15 +439,56 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
 #ifdef ARX_STAMP
         const unsigned long long pts1 = __builtin_readcyclecounter();
 #endif
-        epilogue_store_v3<MODE, (MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS) ? 4 : 8>(acc, ep, m0, n0, wr, wc, lane, M, N, smem + ML::STAGE_OFF + sbuf * EpiStage::BYTES);   // statistics modes: a 4-step residual window keeps the kernel under 256 VGPRs
+        pol.epilogue(acc, m0, n0, wr, wc, lane, smem + ML::STAGE_OFF + sbuf * EpiStage::BYTES);
         if (has_next && wr == 1) ML::bar();
 #ifdef ARX_STAMP
-        if (ep.stamps && (tid == 0 || tid == 256)) {
-            unsigned long long* o = ep.stamps + ((size_t)orig * 2 + (tid >> 8)) * 4;
-            o[0] = pts0; o[1] = pts1; o[2] = __builtin_readcyclecounter(); o[3] = pts0;
-        }
+        pol.stamp(orig, tid, pts0, pts1);
 #endif
         if (!has_next) break;
         orig = onext; m0 = m0n; n0 = n0n; ko = kon; sbuf ^= 1;
     }
+}
+
+// the encoder's linear layers: XCD-banded tile walk, LDS-staged epilogue vectors, fused epilogues (epi3.h)
+template <int MODE, int KROT>
+struct EncoderTilePolicy {
+    static constexpr bool REBASE_W = false;
+    TileWalk walk;
+    const EpiParams& ep;
+    int M, N, nk;
+    __device__ __forceinline__ bool tile(int o, int& m0, int& n0, int& ko) const {
+        int tm = 0, tn = 0;
+        const bool ok = walk.coords(o, tm, tn);
+        m0 = tm * 256; n0 = tn * 256; ko = (tn * KROT) % nk;
+        return ok;
+    }
+    __device__ __forceinline__ void stage_issue(int m0, int n0, char* stage, int wid, int lane) const {
+        epi_stage_issue<MODE>(ep, m0, n0, stage, wid, lane, N);
+    }
+    __device__ __forceinline__ void epilogue(const f32x4 (&acc)[4][8], int m0, int n0, int wr, int wc, int lane, const char* stage) const {
+        // statistics modes: a 4-step residual window keeps the kernel under 256 VGPRs
+        epilogue_store_v3<MODE, (MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS) ? 4 : 8>(acc, ep, m0, n0, wr, wc, lane, M, N, stage);
+    }
+#ifdef ARX_STAMP
+    __device__ __forceinline__ void stamp(int orig, int tid, unsigned long long pts0, unsigned long long pts1) const {
+        if (ep.stamps && (tid == 0 || tid == 256)) {
+            unsigned long long* o = ep.stamps + ((size_t)orig * 2 + (tid >> 8)) * 4;
+            o[0] = pts0; o[1] = pts1; o[2] = __builtin_readcyclecounter(); o[3] = pts0;
+        }
+    }
+#endif
+};
+
+template <int MODE, int KROT = 0>
+__global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                      const bf16_t* __restrict__ W, int64_t ldw,
+                                                                      int M, int N, int K, int tiles_m, int tiles_n, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef ARX_DEV_VARIANTS
+    const TileWalk walk(tiles_m, tiles_n, K, ep.dev_bw);
+#else
+    const TileWalk walk(tiles_m, tiles_n, K);
+#endif
+    const EncoderTilePolicy<MODE, KROT> pol{walk, ep, M, N, K >> 6};
+    gemm8_persistent_body<bf16_t>(A, lda, W, ldw, M, N, K, pol, smem);
 }
