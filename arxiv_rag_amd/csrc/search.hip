@@ -74,6 +74,125 @@ __device__ __forceinline__ void store_query_row(V* __restrict__ dst, const V (&v
     }
 }
 
+// ---- pass-A epilogues as functions of a wave's accumulator tile (shared by the per-tile kernels and the persistent one) --------------
+// fp16 pass: the maximum pass-A score of the wave's 64 corpus rows, per query
+template <int MI, int NI>
+__device__ __forceinline__ void groupmax_epilogue_f16(const f32x4 (&acc)[NI][MI], float* __restrict__ gmax_row, int m_first, int nq, int lane) {
+    float gm[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[j][i][r]);
+        gm[i] = max_over_rows(mx);
+    }
+    store_query_row<MI, float>(gmax_row, gm, m_first, nq, lane);
+}
+
+// aux word per (query, group), beside the group's upper bound: the SECOND largest row bound of the group rounded UP to 16 bits (bf16
+// image, still an upper bound) in the high half, the position (0..63) of the row that holds the largest bound in the low bits.  When the
+// second bound is below a query's threshold, only that one row of the group can reach the top-k: the candidate step then reads ONE
+// fp16 row (1.5 KB at D = 768) instead of the group's 64 (98 KB) — on unit rows that is the case for all but a handful of the ~150
+// candidate groups per query, and it is what lets the int8 pass pay above the ridge point too (profiles/r03).
+__device__ __forceinline__ uint32_t pack_aux(float ub2, int arg_row) {
+    const uint32_t b = __float_as_uint(ub2);
+    const uint32_t up = (b & 0x80000000u) ? (b & 0xFFFF0000u)                      // negative: dropping mantissa bits moves towards zero = up
+                                          : ((b + 0xFFFFu) & 0xFFFF0000u);         // positive: round the magnitude up
+    return up | (uint32_t)(arg_row & 63);
+}
+
+// int8 pass (see "int8 PRE-FILTER" below for the bound): upper bound of the group + aux word, per query.
+//   this lane's 16 corpus rows: wave's group row j*16 + (lane>>4)*4 + r   (acc[j][i][r]); cm_of(j, c4) gives their (s_c, L1) pairs,
+//   qm_of(i) the (s_q, L1) of query block i.
+// ub(q, c) = s_q * [ s_c * (dot + cq) + X_c ],  cq = ceil(0.5001 L1(q8)) (an integer: added to the exact int32 dot),
+// X_c = s_c * (0.5001 L1(c8) + 0.2501 D) inflated by 2^-22 (its two roundings).  Three instructions per element (integer add,
+// convert — exact below 2^24 —, ONE fma = one rounding of the exact value); s_q > 0 and the rounding allowance are monotone, so
+// the group's two largest bounds are reduced FIRST and scaled / inflated afterwards, on two values instead of sixteen.
+template <int MI, int NI, typename CM, typename QM>
+__device__ __forceinline__ void groupmax_epilogue_i8(const f32x4 (&acc)[NI][MI], CM cm_of, QM qm_of, int D, float* __restrict__ gmax_row,
+                                                     uint32_t* __restrict__ aux_row, int m_first, int nq, int lane) {
+    float sc[NI][4], xc[NI][4];
+    const float dterm = 0.2501f * (float)D;
+    const int lrow = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        float2 c4[4];
+        cm_of(j, c4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[j][r] = c4[r].x;
+            const float x = c4[r].x * fmaf(0.5001f, c4[r].y, dterm);
+            xc[j][r] = fmaf(x, 2.4e-7f, x);
+        }
+    }
+    float gm[MI];
+    uint32_t ga[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const float2 qm = qm_of(i);
+        const int cqi = (int)ceilf(0.5001f * qm.y) + 1;
+        // top-2 of the 16 bounds with the arg-max for free: the low 6 bits of each value's float image are REPLACED by the row's
+        // position in the group (j*16 + r; the lane's 4-row offset is OR-ed in after the lane-local pass), which moves a value by at
+        // most 63 ulp either way — covered by the 2^-17 allowance below — and lets v_max / v_med3 carry the index along.
+        float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const i32x4 it = __builtin_bit_cast(i32x4, acc[j][i]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u = fmaf(sc[j][r], (float)(it[r] + cqi), xc[j][r]);
+                const float key = __uint_as_float((__float_as_uint(u) & ~63u) | (uint32_t)(j * 16 + r));
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, key);               // second largest of {m1 >= m2, key}
+                m1 = fmaxf(m1, key);
+            }
+        }
+        m1 = __uint_as_float(__float_as_uint(m1) | (uint32_t)lrow);
+        m2 = __uint_as_float(__float_as_uint(m2) | (uint32_t)lrow);
+        {
+            float a1, b1, a2, b2;
+            rows16(m1, a1, b1); rows16(m2, a2, b2);
+            m1 = fmaxf(a1, b1); m2 = fmaxf(fmaxf(a2, b2), fminf(a1, b1));
+            rows32(m1, a1, b1); rows32(m2, a2, b2);
+            m1 = fmaxf(a1, b1); m2 = fmaxf(fmaxf(a2, b2), fminf(a1, b1));
+        }
+        const int i1 = (int)(__float_as_uint(m1) & 63u);
+        float b1 = m1 * qm.x, b2 = m2 * qm.x;
+        b1 += fabsf(b1) * 8.0e-6f + 1e-12f;                              // 63 ulp of the index bits (2^-17.4) + the fma's and this product's roundings
+        b2 += fabsf(b2) * 8.0e-6f + 1e-12f;
+        gm[i] = b1; ga[i] = pack_aux(b2, i1);
+    }
+    store_query_row<MI, float>(gmax_row, gm, m_first, nq, lane);
+    store_query_row<MI, uint32_t>(aux_row, ga, m_first, nq, lane);
+}
+// (s_c, L1) pairs / (s_q, L1) pairs read from an LDS stage: [512 floats] the tile's 256 corpus rows, then [2 x 256] its queries
+struct MetaFromLds {
+    const float* meta; int wn, lrow;
+    __device__ __forceinline__ void operator()(int j, float2 (&c4)[4]) const {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(meta + (wn * GROUP_ROWS + j * 16 + lrow) * 2);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(meta + (wn * GROUP_ROWS + j * 16 + lrow) * 2 + 4);
+        c4[0] = float2{lo[0], lo[1]}; c4[1] = float2{lo[2], lo[3]}; c4[2] = float2{hi[0], hi[1]}; c4[3] = float2{hi[2], hi[3]};
+    }
+};
+// one 4-byte LDS-DMA per thread stages the tile's corpus pairs, one more its query pairs (BM queries from m0)
+template <int BM>
+__device__ __forceinline__ void stage_i8_meta(const float2* __restrict__ cmeta, const float2* __restrict__ qmeta, int64_t n0, int64_t n_rows,
+                                              int m0, int nq, float* meta, int tid) {
+    {
+        int64_t e = n0 * 2 + tid;                                          // dword index into cmeta; rows past the shard repeat its last row
+        const int64_t last = n_rows * 2 - 2 + (tid & 1);
+        e = e < last ? e : last;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const float*>(cmeta) + e), (lds_void_t*)(meta + (tid & ~63)), 4, 0, 0);
+    }
+    if (tid < 2 * BM) {                                                    // wave-uniform (BM is a multiple of 32)
+        int e = m0 * 2 + tid;
+        const int last = nq * 2 - 2 + (tid & 1);
+        e = e < last ? e : last;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const float*>(qmeta) + e), (lds_void_t*)(meta + 512 + (tid & ~63)), 4, 0, 0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // pass A
 template <int BM, bool GLDS>
@@ -105,17 +224,7 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
     const int wm = wid / 4, wn = wid % 4;
     if (wn * GROUP_ROWS >= rows_here) return;
     const int64_t g = (n0 >> 6) + wn;
-    float gm[ML::MI];
-#pragma unroll
-    for (int i = 0; i < ML::MI; ++i) {
-        float mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < ML::NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[j][i][r]);
-        gm[i] = max_over_rows(mx);
-    }
-    store_query_row<ML::MI, float>(gmax + g * ldg, gm, m0 + wm * ML::TM, nq, lane);
+    groupmax_epilogue_f16<ML::MI, ML::NI>(acc, gmax + g * ldg, m0 + wm * ML::TM, nq, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -162,18 +271,6 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __re
     if (lane == 0) meta[row] = float2{s, l1};
 }
 
-// aux word per (query, group), beside the group's upper bound: the SECOND largest row bound of the group rounded UP to 16 bits (bf16
-// image, still an upper bound) in the high half, the position (0..63) of the row that holds the largest bound in the low bits.  When the
-// second bound is below a query's threshold, only that one row of the group can reach the top-k: the candidate step then reads ONE
-// fp16 row (1.5 KB at D = 768) instead of the group's 64 (98 KB) — on unit rows that is the case for all but a handful of the ~150
-// candidate groups per query, and it is what lets the int8 pass pay above the ridge point too (profiles/r03).
-__device__ __forceinline__ uint32_t pack_aux(float ub2, int arg_row) {
-    const uint32_t b = __float_as_uint(ub2);
-    const uint32_t up = (b & 0x80000000u) ? (b & 0xFFFF0000u)                      // negative: dropping mantissa bits moves towards zero = up
-                                          : ((b + 0xFFFFu) & 0xFFFF0000u);         // positive: round the magnitude up
-    return up | (uint32_t)(arg_row & 63);
-}
-
 template <int BM, bool GLDS>
 __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* __restrict__ Q8, const float2* __restrict__ qmeta, int nq,
                                                                   const int8_t* __restrict__ C8, const float2* __restrict__ cmeta,
@@ -204,19 +301,7 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
     const int lrow = (lane >> 4) * 4;
     float2 cmr[META_LDS ? 1 : ML::NI][META_LDS ? 1 : 4], qmr[META_LDS ? 1 : ML::MI];
     if constexpr (META_LDS) {
-        const int tid = threadIdx.x;
-        {
-            int64_t e = n0 * 2 + tid;                                          // dword index into cmeta; rows past the shard repeat its last row
-            const int64_t last = n_rows * 2 - 2 + (tid & 1);
-            e = e < last ? e : last;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const float*>(cmeta) + e), (lds_void_t*)(meta + (tid & ~63)), 4, 0, 0);
-        }
-        if (tid < 2 * BM) {                                                    // wave-uniform (BM is a multiple of 32)
-            int e = m0 * 2 + tid;
-            const int last = nq * 2 - 2 + (tid & 1);
-            e = e < last ? e : last;
-            __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const float*>(qmeta) + e), (lds_void_t*)(meta + 512 + (tid & ~63)), 4, 0, 0);
-        }
+        stage_i8_meta<BM>(cmeta, qmeta, n0, n_rows, m0, nq, meta, threadIdx.x);
     } else {
 #pragma unroll
         for (int j = 0; j < ML::NI; ++j)
@@ -242,71 +327,68 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
         ML::run(Q, Dh, nq, C + n0 * Dh, Dh, rows_here, Dh, m0, 0, smem, acc, tile_q * 2);
     if (wn * GROUP_ROWS >= rows_here) return;
     const int64_t g = (n0 >> 6) + wn;
-    // this lane's 16 corpus rows: n0 + wn*64 + j*16 + (lane>>4)*4 + r   (acc[j][i][r])
-    // ub(q, c) = s_q * [ s_c * (dot + cq) + X_c ],  cq = ceil(0.5001 L1(q8)) (an integer: added to the exact int32 dot),
-    // X_c = s_c * (0.5001 L1(c8) + 0.2501 D) inflated by 2^-22 (its two roundings).  Three instructions per element (integer add,
-    // convert — exact below 2^24 —, ONE fma = one rounding of the exact value); s_q > 0 and the rounding allowance are monotone, so
-    // the group's two largest bounds are reduced FIRST and scaled / inflated afterwards, on two values instead of sixteen.
-    float sc[ML::NI][4], xc[ML::NI][4];
-    const float dterm = 0.2501f * (float)D;
+    if constexpr (META_LDS) {
+        const float* qmeta_l = meta + 512 + (wm * ML::TM + (lane & 15)) * 2;
+        groupmax_epilogue_i8<ML::MI, ML::NI>(acc, MetaFromLds{meta, wn, lrow},
+                                             [&](int i) { return *reinterpret_cast<const float2*>(qmeta_l + i * 32); },
+                                             D, gmax + g * ldg, aux + g * ldg, m0 + wm * ML::TM, nq, lane);
+    } else {
+        groupmax_epilogue_i8<ML::MI, ML::NI>(acc, [&](int j, float2 (&c4)[4]) {
 #pragma unroll
-    for (int j = 0; j < ML::NI; ++j) {
-        float2 c4[4];
-        if constexpr (META_LDS) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(meta + (wn * GROUP_ROWS + j * 16 + lrow) * 2);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(meta + (wn * GROUP_ROWS + j * 16 + lrow) * 2 + 4);
-            c4[0] = float2{lo[0], lo[1]}; c4[1] = float2{lo[2], lo[3]}; c4[2] = float2{hi[0], hi[1]}; c4[3] = float2{hi[2], hi[3]};
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c4[r] = cmr[j][r];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sc[j][r] = c4[r].x;
-            const float x = c4[r].x * fmaf(0.5001f, c4[r].y, dterm);
-            xc[j][r] = fmaf(x, 2.4e-7f, x);
-        }
+                                                 for (int r = 0; r < 4; ++r) c4[r] = cmr[j][r];
+                                             },
+                                             [&](int i) { return qmr[i]; }, D, gmax + g * ldg, aux + g * ldg, m0 + wm * ML::TM, nq, lane);
     }
-    float gm[ML::MI];
-    uint32_t ga[ML::MI];
-#pragma unroll
-    for (int i = 0; i < ML::MI; ++i) {
-        float2 qm;
-        if constexpr (META_LDS) qm = *reinterpret_cast<const float2*>(meta + 512 + (wm * ML::TM + i * 16 + (lane & 15)) * 2);
-        else qm = qmr[i];
-        const int cqi = (int)ceilf(0.5001f * qm.y) + 1;
-        // top-2 of the 16 bounds with the arg-max for free: the low 6 bits of each value's float image are REPLACED by the row's
-        // position in the group (j*16 + r; the lane's 4-row offset is OR-ed in after the lane-local pass), which moves a value by at
-        // most 63 ulp either way — covered by the 2^-17 allowance below — and lets v_max / v_med3 carry the index along.
-        float m1 = -INFINITY, m2 = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < ML::NI; ++j) {
-            const i32x4 it = __builtin_bit_cast(i32x4, acc[j][i]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float u = fmaf(sc[j][r], (float)(it[r] + cqi), xc[j][r]);
-                const float key = __uint_as_float((__float_as_uint(u) & ~63u) | (uint32_t)(j * 16 + r));
-                m2 = __builtin_amdgcn_fmed3f(m1, m2, key);               // second largest of {m1 >= m2, key}
-                m1 = fmaxf(m1, key);
-            }
-        }
-        m1 = __uint_as_float(__float_as_uint(m1) | (uint32_t)lrow);
-        m2 = __uint_as_float(__float_as_uint(m2) | (uint32_t)lrow);
-        {
-            float a1, b1, a2, b2;
-            rows16(m1, a1, b1); rows16(m2, a2, b2);
-            m1 = fmaxf(a1, b1); m2 = fmaxf(fmaxf(a2, b2), fminf(a1, b1));
-            rows32(m1, a1, b1); rows32(m2, a2, b2);
-            m1 = fmaxf(a1, b1); m2 = fmaxf(fmaxf(a2, b2), fminf(a1, b1));
-        }
-        const int i1 = (int)(__float_as_uint(m1) & 63u);
-        float b1 = m1 * qm.x, b2 = m2 * qm.x;
-        b1 += fabsf(b1) * 8.0e-6f + 1e-12f;                              // 63 ulp of the index bits (2^-17.4) + the fma's and this product's roundings
-        b2 += fabsf(b2) * 8.0e-6f + 1e-12f;
-        gm[i] = b1; ga[i] = pack_aux(b2, i1);
+}
+
+// ---- pass A, persistent form (>= 256 queries, even number of k-tiles): gemm8.h's persistent 4-phase loop with the pass-A epilogues.
+// Above the ridge point a 256 x 256 x D tile is SHORT (12 k-tiles of f16, 6 of int8 at D = 768): the per-tile kernel pays the first
+// loads' latency, an idle matrix pipe during the epilogue and a block launch per tile — 29 k cycles per int8 tile against 6 k of matrix
+// work (profiles/r03).  Here one block per CU walks its tiles with the operand stream running through the tile boundaries.
+// Tile order: block b belongs to XCD b % 8 and takes corpus tiles = b % 8 (mod 8); inside an XCD the sequence is query-tile fastest, so
+// the (up to four) blocks that read one corpus tile are neighbours in time on ONE L2.
+template <bool I8>
+struct SearchTilePolicy {
+    static constexpr bool REBASE_W = true;
+    int tiles_q, tiles_n, nq, D;
+    int64_t n_rows, ldg;
+    float* gmax;
+    uint32_t* aux;
+    const float2* qmeta; const float2* cmeta;
+    __device__ __forceinline__ bool tile(int o, int& m0, int& n0, int& ko) const {
+        const int x = o & 7, L = o >> 3;
+        const int tq = L % tiles_q, tn = (L / tiles_q) * 8 + x;
+        m0 = tq * 256; n0 = tn * 256; ko = 0;
+        return tn < tiles_n;
     }
-    store_query_row<ML::MI, float>(gmax + g * ldg, gm, m0 + wm * ML::TM, nq, lane);
-    store_query_row<ML::MI, uint32_t>(aux + g * ldg, ga, m0 + wm * ML::TM, nq, lane);
+    __device__ __forceinline__ void stage_issue(int m0, int n0, char* stage, int wid, int lane) const {
+        if constexpr (I8) stage_i8_meta<256>(cmeta, qmeta, n0, n_rows, m0, nq, reinterpret_cast<float*>(stage), wid * 64 + lane);
+    }
+    __device__ __forceinline__ void epilogue(const f32x4 (&acc)[4][8], int m0, int n0, int wr, int wc, int lane, const char* stage) const {
+        if ((int64_t)n0 + wc * GROUP_ROWS >= n_rows) return;             // the wave's group lies past the shard (wave-uniform)
+        const int64_t g = ((int64_t)n0 >> 6) + wc;
+        if constexpr (I8) {
+            const float* meta = reinterpret_cast<const float*>(stage);
+            const float* qmeta_l = meta + 512 + (wr * 128 + (lane & 15)) * 2;
+            groupmax_epilogue_i8<8, 4>(acc, MetaFromLds{meta, wc, (lane >> 4) * 4},
+                                       [&](int i) { return *reinterpret_cast<const float2*>(qmeta_l + i * 32); },
+                                       D, gmax + g * ldg, aux + g * ldg, m0 + wr * 128, nq, lane);
+        } else
+            groupmax_epilogue_f16<8, 4>(acc, gmax + g * ldg, m0 + wr * 128, nq, lane);
+    }
+#ifdef ARX_STAMP
+    __device__ __forceinline__ void stamp(int, int, unsigned long long, unsigned long long) const {}
+#endif
+};
+
+template <typename T, bool I8>
+__global__ __launch_bounds__(512) void search_groupmax_persistent_kernel(const T* __restrict__ Q, int nq, const T* __restrict__ C, int64_t n_rows,
+                                                                          int Kt /* row length in T elements */, int D, int tiles_q, int tiles_n,
+                                                                          const float2* __restrict__ qmeta, const float2* __restrict__ cmeta,
+                                                                          float* __restrict__ gmax, uint32_t* __restrict__ aux, int64_t ldg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const SearchTilePolicy<I8> pol{tiles_q, tiles_n, nq, D, n_rows, ldg, gmax, aux, qmeta, cmeta};
+    gemm8_persistent_body<T>(Q, Kt, C, Kt, nq, (int)n_rows, Kt, pol, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -993,6 +1075,27 @@ static int launch_groupmax_i8(const int8_t* Q8, const float2* qmeta, int nq, con
     return ARX_OK;
 }
 
+// pass A in persistent form: >= 256 queries per pass, an even number of 64-element k-tiles, rows addressable as int
+template <typename T, bool I8>
+static int launch_groupmax_persistent(const T* Q, int nq, const T* C, int64_t n_rows, int Kt, int D, const float2* qmeta, const float2* cmeta,
+                                      float* gmax, uint32_t* aux, int64_t ldg, hipStream_t st) {
+    auto kern = search_groupmax_persistent_kernel<T, I8>;
+    constexpr int smem_bytes = Gemm8Phase<T, 0>::SMEM_BYTES;
+    ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem_bytes));
+    const int tq = cdiv(nq, 256);
+    const int64_t tn = (n_rows + 255) / 256;
+    const int n_cu = arx_device_cus();
+    int64_t grid = tq * tn < n_cu ? tq * tn : n_cu;
+    grid = grid / 8 * 8 > 0 ? grid / 8 * 8 : 8;                   // a multiple of 8: a block keeps its XCD (and its residue class of corpus tiles)
+    kern<<<(int)grid, 512, smem_bytes, st>>>(Q, nq, C, n_rows, Kt, D, tq, (int)tn, qmeta, cmeta, gmax, aux, ldg);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+static bool persistent_pass_ok(int nq, int64_t n_rows, int k_elems) {
+    static const bool off = getenv("ARX_SEARCH_PERSISTENT") && getenv("ARX_SEARCH_PERSISTENT")[0] == '0';      // A/B switch
+    return !off && nq > 128 && n_rows < (1ll << 31) - 256 && k_elems % 128 == 0 && (int64_t)k_elems * 2 * 256 < (1ll << 31);
+}
+
 static int64_t i8_meta_offset(int64_t n_rows, int dim) { return round_up64(n_rows * (int64_t)dim, 256); }
 
 extern "C" int64_t arx_topk_i8_index_bytes(int64_t n_rows, int32_t dim) {
@@ -1126,6 +1229,10 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
             const float2* cmeta = (const float2*)((const char*)index_i8 + i8_meta_offset(n_rows, dim));
             ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
             uint32_t* aux = (uint32_t*)((char*)ws + L.aux);
+            if (persistent_pass_ok(nq, n_rows, dim / 2))
+                rc = launch_groupmax_persistent<i8pair_t, true>((const i8pair_t*)q8, nq, (const i8pair_t*)C8, n_rows, dim / 2, dim, qmeta, cmeta, gmax,
+                                                                aux, L.ldg, st);
+            else
             rc = nq <= 64 ? launch_groupmax_i8<64, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
                : nq <= 128 ? launch_groupmax_i8<128, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
                            : launch_groupmax_i8<256, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st);
@@ -1138,6 +1245,9 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
                            : launch_groupmax<256, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, st);
         } else
 #endif
+            if (persistent_pass_ok(nq, n_rows, dim))
+                rc = launch_groupmax_persistent<f16_t, false>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, gmax, nullptr, L.ldg, st);
+            else
             rc = nq <= 64 ? launch_groupmax<64, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
                : nq <= 128 ? launch_groupmax<128, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
                            : launch_groupmax<256, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st);
