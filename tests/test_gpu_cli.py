@@ -234,3 +234,26 @@ def test_sharded_branch_single_rank_nccl(nccl_world1, tmp_path, monkeypatch):
     assert torch.equal(sink2.rows.cpu(), torch.from_numpy(rows2.astype(np.float16)))
     model.encoder.close()
     GEN._model, GEN._model_name = None, None
+
+
+def test_bench_starts_its_own_rank_and_prints_one_json_line(hip):
+    """`python bench.py --gpus N` as the driver calls it (no RANK in the environment) must start its ranks itself as child processes
+    and still print exactly ONE JSON line.  Rehearsed with the one GPU there is: ARX_BENCH_FORCE_LAUNCH=1 sends N = 1 down the same
+    child-launch path (torch.distributed.run, RCCL group of one rank, all-gather + merge of the partial top-k); small shapes."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ARX_BENCH_FORCE_LAUNCH"] = "1"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64",
+                        "--sustained-chunks", "0", "--no-cpu-baseline", "--no-query-leg", "--search-rows", "200000",
+                        "--search-total-rows", "100000", "--d1024-rows", "0", "--search-queries", "300"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
+    st = d["search"]["strong_scaling"]
+    assert st["merged_vs_single_index"] == {"queries": 64, "ids_equal": True, "scores_equal": True}
+    assert "allgather_plus_merge_ms" in st["results"]["Qb=64"] and st["results"]["Qb=64"]["qps_pipelined"] > 0
