@@ -236,10 +236,10 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
 //   absorbs the fp32 division).  For a query q = s_q q8 + f and a corpus row c = s_c c8 + e:
 //       q.c = s_q s_c (q8.c8) + q^.e + f.c^ + f.e ,   |q^.e| <= 0.5001 s_c |q^|_1 ,  |f.c^| <= 0.5001 s_q |c^|_1 ,  |f.e| <= 0.2501 D s_q s_c
 //   with |q^|_1 = s_q L1(q8), |c^|_1 = s_c L1(c8):   q.c <= s_q s_c ( q8.c8 + 0.5001 (L1(q8) + L1(c8)) + 0.2501 D ) =: ub.
-// q8.c8 is an exact int32 (|.| <= 127^2 D < 2^24: exact as fp32 too); the four fp32 operations that form ub are covered by a 2^-20
-// relative inflation.  The certificate then reads: every unscored row's TRUE score <= U; U < s_k - tau => the answer is exact.  With
-// unit rows the slack is ~0.026, so a few hundred groups per query reach the threshold and are rescored by the certificate's
-// exhaustive-by-threshold step (one block per query, all its waves) — a few per cent of the bytes the int8 pass saves.
+// q8.c8 is an exact int32 (|.| <= 127^2 D < 2^24: exact as fp32 too); how the bound is evaluated and its roundings covered: see
+// groupmax_epilogue_i8.  The certificate then reads: every unscored row's TRUE score <= U; U < s_k - tau => the answer is exact.  With
+// unit rows the slack is ~0.026, so ~150 groups per query reach the threshold; the candidate pipeline below (collect_pairs_kernel ->
+// pair_rescore_kernel -> merge_survivors_kernel) rescoring ONE row of almost every such group (aux word) settles them.
 __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __restrict__ X, int64_t n_rows, int D, int8_t* __restrict__ X8,
                                                                 float2* __restrict__ meta) {
     const int lane = threadIdx.x & 63;
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
                                                       float* __restrict__ thr_out, int32_t* __restrict__ selg_out,
                                                       const int32_t* __restrict__ only_if, int* __restrict__ cand_counters,
                                                       int* __restrict__ cand_nsurv) {
-    // thr_out / selg_out (int8 pre-filter, small query batches): COLLECT mode — write the provisional top-k, the threshold s_k - tau
+    // thr_out / selg_out (int8 pre-filter): COLLECT mode — write the provisional top-k, the threshold s_k - tau
     // and the K rescored groups, and leave the rest to collect_pairs / pair_rescore / merge_survivors (the in-block fallback below
     // walks this query's gmax column from ONE CU: fine for the rare uncertified query, far too slow when every query needs it).
     // only_if: run only for the queries it flags (the overflow re-run of that pipeline).
@@ -1143,7 +1143,7 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
         ARX_HIP_CHECK(hipGetLastError());
         return ARX_OK;
     }
-    // int8 pre-filter, <= 128 queries: provisional top-k + threshold, then the candidate pipeline, then (only for queries whose
+    // int8 pre-filter: provisional top-k + threshold, then the candidate pipeline, then (only for queries whose
     // lists overflowed) the exhaustive kernel
     float* thr = (float*)(ws + L.thr);
     int32_t* selg = (int32_t*)(ws + L.selg);
