@@ -351,7 +351,12 @@ static int launch_gemm(int cls, int variant, const uint16_t* A, int64_t lda, con
     if (variant == 70) return launch_gemm_small<MODE>(A, lda, W, ldw, M, N, K, ep, small_ws, st);      // small-batch path (gemm_small.h)
 #ifdef ARX_DEV_VARIANTS
     static const int dev_bw = getenv("ARX_DEV_BW") ? atoi(getenv("ARX_DEV_BW")) : 0;      // dev A/B in situ: tile-walk band width
-    if (dev_bw) { EpiParams e2 = ep; e2.dev_bw = dev_bw; return arx_launch_gemm<MODE>(variant, A, lda, W, ldw, M, N, K, e2, st); }
+    const char* stg = getenv("ARX_DEV_STAGGER");      // "cycles[,slots[,store]]"
+    if (dev_bw || stg) {
+        EpiParams e2 = ep; e2.dev_bw = dev_bw;
+        if (stg) { int a = 0, b = 8, c = 0; sscanf(stg, "%d,%d,%d", &a, &b, &c); e2.dev_stagger = a; e2.dev_slots = b > 0 ? b : 8; e2.dev_store = c; }
+        return arx_launch_gemm<MODE>(variant, A, lda, W, ldw, M, N, K, e2, st);
+    }
 #endif
     return arx_launch_gemm<MODE>(variant, A, lda, W, ldw, M, N, K, ep, st);
 }
@@ -367,35 +372,49 @@ extern "C" int32_t arx_gemm_bf16(const void* A, const void* W, const float* bias
 #ifdef ARX_DEV_VARIANTS
     // dev A/B encoding: variant = schedule + 100 * store mode (1 nt, 2 sc1) + 1000 * band width of the tile walk
     ep.dev_store = (variant / 100) % 10; ep.dev_bw = variant / 1000; variant %= 100;
+    if (const char* stg = getenv("ARX_DEV_STAGGER")) { int a = 0, b = 8; sscanf(stg, "%d,%d", &a, &b); ep.dev_stagger = a; ep.dev_slots = b > 0 ? b : 8; }
 #endif
 #ifdef ARX_STAMP
     {   // dev build: per-tile cycle stamps of one launch, summarised on stderr
         static unsigned long long* d = nullptr;
         const int tiles = cdiv(M, 256) * cdiv(N, 256);
-        if (!d) ARX_HIP_CHECK(hipMalloc(&d, (size_t)8 * 4 * 2 * 65536));
-        if (getenv("ARX_STAMP_DUMP") && tiles <= 65536) {
+        if (!d) ARX_HIP_CHECK(hipMalloc(&d, (size_t)8 * 32 * 2 * 16384));
+        if (getenv("ARX_STAMP_DUMP") && tiles <= 16384) {
             ep.stamps = d;
             int rc = ARX_ERR_ARG;
             if (mode == EPI_BIAS) rc = arx_launch_gemm<EPI_BIAS>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
             if (mode == EPI_BIAS_GELU) rc = arx_launch_gemm<EPI_BIAS_GELU>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
             if (mode == EPI_BIAS_RESID) rc = arx_launch_gemm<EPI_BIAS_RESID>(variant, (const uint16_t*)A, K, (const uint16_t*)W, K, M, N, K, ep, st);
             ARX_HIP_CHECK(hipStreamSynchronize(st));
-            std::vector<unsigned long long> hbuf((size_t)tiles * 8);
+            std::vector<unsigned long long> hbuf((size_t)tiles * 64);
             ARX_HIP_CHECK(hipMemcpy(hbuf.data(), d, hbuf.size() * 8, hipMemcpyDeviceToHost));
-            double loop[2] = {0, 0}, epi[2] = {0, 0}, pro[2] = {0, 0};
+            double loop[2] = {0, 0}, epi[2] = {0, 0}, pro[2] = {0, 0}, x45[2] = {0, 0}, x67[2] = {0, 0};
             unsigned long long tmin = ~0ull, tmax = 0;
             for (int t = 0; t < tiles; ++t)
                 for (int g = 0; g < 2; ++g) {
-                    const unsigned long long* o = &hbuf[((size_t)t * 2 + g) * 4];
+                    const unsigned long long* o = &hbuf[((size_t)t * 2 + g) * 32];
                     loop[g] += (double)(o[1] - o[3]); epi[g] += (double)(o[2] - o[1]); pro[g] += (double)(o[3] - o[0]);
+                    if (variant == 9) { x45[g] += (double)(o[5] - o[4]); x67[g] += (double)(o[7] - o[6]); }      // stall in the counted wait of k-tile 0 / 1
+                    else x45[g] += (double)(o[4] - o[2]);                                                        // per-tile: last store issued -> all acknowledged
                     tmin = o[0] < tmin ? o[0] : tmin; tmax = o[2] > tmax ? o[2] : tmax;
                 }
             if (variant == 9) {   // persistent: tile t+256 follows tile t on the same CU -> gap between epilogue end and next loop start, tile period
                 double gap = 0, period = 0; int n = 0;
-                for (int t = 0; t + 256 < tiles; ++t) { const unsigned long long* a = &hbuf[(size_t)t * 8]; const unsigned long long* b = &hbuf[(size_t)(t + 256) * 8];
+                for (int t = 0; t + 256 < tiles; ++t) { const unsigned long long* a = &hbuf[(size_t)t * 64]; const unsigned long long* b = &hbuf[(size_t)(t + 256) * 64];
                     gap += (double)(b[0] - a[2]); period += (double)(b[0] - a[0]); ++n; }
                 if (n) fprintf(stderr, "[stamp] persistent: g0 tile period %.0f clk, epilogue-end -> next loop start %.0f clk\n", period / n, gap / n);
             }
+            if (const char* sf = getenv("ARX_STAMP_FILE")) {      // raw stamps for offline analysis: [tiles][2 groups][32] u64
+                if (FILE* f = fopen(sf, "wb")) { fwrite(hbuf.data(), 8, hbuf.size(), f); fclose(f); }
+            }
+            if (variant == 9) {      // k-tile start to k-tile start, first 16 k-tiles, group 0 (tiles after a CU's first)
+                const int nkt = K / 64 < 16 ? K / 64 : 16;
+                fprintf(stderr, "[stamp] k-tile durations g0:");
+                for (int k = 0; k + 1 < nkt; ++k) { double a = 0; int n = 0; for (int t = 256; t < tiles; ++t) { const unsigned long long* o = &hbuf[(size_t)t * 64]; a += (double)(o[9 + k] - o[8 + k]); ++n; } fprintf(stderr, " %.0f", a / (n ? n : 1)); }
+                fprintf(stderr, "\n");
+            }
+            fprintf(stderr, "[stamp] %s g0 %.0f g1 %.0f clk%s g0 %.0f g1 %.0f\n", variant == 9 ? "wait at k-tile 0:" : "store drain after the epilogue:", x45[0] / tiles, x45[1] / tiles,
+                    variant == 9 ? ", at k-tile 1:" : " (-)", x67[0] / tiles, x67[1] / tiles);
             fprintf(stderr, "[stamp] M=%d N=%d K=%d mode=%d tiles=%d: prologue %.0f / %.0f, loop g0 %.0f g1 %.0f clk, epilogue g0 %.0f g1 %.0f clk, span %.0f clk, tiles/CU %.1f\n",
                     M, N, K, mode, tiles, pro[0] / tiles, pro[1] / tiles, loop[0] / tiles, loop[1] / tiles, epi[0] / tiles, epi[1] / tiles, (double)(tmax - tmin), tiles / 256.0);
             return rc;

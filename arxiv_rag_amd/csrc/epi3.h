@@ -39,6 +39,18 @@ __device__ __forceinline__ void epi_stage_issue(const EpiParams& p, int m0, int 
     if (src) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + l * 4), (lds_void_t*)(stage + w * 1024), 16, 0, 0);
 }
 
+// Full-line stores (below) pay eight DPP moves per row block: worth it everywhere (same-box A/B in situ: QKV -2.4 %, O-projection -2.8 %,
+// FFN-2 -0.5 % against 64-B half-line stores) except in the GELU epilogues, which are bound by their VALU work (FFN-1 +6 %).
+template <int MODE> struct EpiFullLine {
+#if defined(ARX_FL_ALL)
+    static constexpr bool value = true;
+#elif defined(ARX_FL_NONE)
+    static constexpr bool value = false;
+#else
+    static constexpr bool value = !(MODE == EPI_BIAS_GELU || MODE == EPI_LN_BIAS_GELU);
+#endif
+};
+
 template <int MODE, bool CHECK, int DEPTH>
 __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8], const EpiParams& p, int m0, int n0, int wr, int wc,
                                                        int lane, int M, const char* stage) {
@@ -47,14 +59,17 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
     constexpr bool STATS = (MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS);
     constexpr bool RESID = (MODE == EPI_BIAS_RESID || STATS);
     constexpr bool LNR = (MODE == EPI_LNRESID_STATS);
-    const int mq = lane & 15, q = lane >> 4, odd = q & 1;
+    constexpr bool FL = EpiFullLine<MODE>::value;
+    const int mq = lane & 15, q = lane >> 4;
     const int m_base = m0 + wr * 128, n_base = n0 + wc * 64;
     const float* sf = reinterpret_cast<const float*>(stage);
     // row offsets are rebuilt per step from one base (block-uniform strides): the epilogue must stay well under 256 VGPRs or
     // the persistent kernel's loop-carried state gets spilled INTO the k-loop
     auto row_of = [&](int i) { int m = m_base + i * 16 + mq; if (CHECK) m = m < M ? m : M - 1; return m; };
     auto row_ok = [&](int i) { return !CHECK || (m_base + i * 16 + mq) < M; };
-    auto col_of = [&](int jp) { return wc * 64 + (2 * jp + odd) * 16 + (q >> 1) * 8; };     // column inside the block tile
+    // column inside the block tile: with the permuted W placement (gemm8.h b_slice_col) this lane's values of MFMA blocks 2jp and 2jp + 1
+    // are the eight consecutive columns jp * 32 + q * 8 + [0, 8) — no cross-lane exchange, and the 4 lanes of a row cover 64 contiguous bytes
+    auto col_of = [&](int jp) { return wc * 64 + jp * 32 + q * 8; };
     u32x4 rres[DEPTH];
     auto res_load = [&](int st) {
         const int i = st / (NI / 2), jp = st % (NI / 2);
@@ -68,6 +83,7 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
     // column vectors are simply re-read from the LDS stage each step (three to six ds_read_b128)
     float st_s = 0.f, st_q = 0.f;
     f32x2 bb[4], ss[4], gg[4], ee[4];
+    u32x4 opair[2];
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
         const int i = st / (NI / 2), jp = st % (NI / 2);
@@ -86,14 +102,8 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
                 ee[0] = f32x2{e0[0], e0[1]}; ee[1] = f32x2{e0[2], e0[3]}; ee[2] = f32x2{e1[0], e1[1]}; ee[3] = f32x2{e1[2], e1[3]};
             }
         }
-        f32x4 lo, hi;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * jp][i][r]),
-                                                             __float_as_uint(acc[2 * jp + 1][i][r]), false, false);
-            lo[r] = __uint_as_float(sw[0]); hi[r] = __uint_as_float(sw[1]);
-        }
-        if (row_ok(i)) {
+        const f32x4 lo = acc[2 * jp][i], hi = acc[2 * jp + 1][i];
+        if (FL || row_ok(i)) {                                       // full-line stores: every lane computes, its piece may be stored by its partner lane
             const int rb = wr * 128 + i * 16 + mq;                            // row inside the block tile
             f32x2 vv[4] = {f32x2{lo[0], lo[1]}, f32x2{lo[2], lo[3]}, f32x2{hi[0], hi[1]}, f32x2{hi[2], hi[3]}};
             if constexpr (LN_IN) {
@@ -125,10 +135,40 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
             u32x4 o;
 #pragma unroll
             for (int pi = 0; pi < 4; ++pi) o[pi] = pack_bf16x2(vv[pi].x, vv[pi].y);
-            {
+            if constexpr (FL) {
+              opair[jp] = o;
+              if (jp == NI / 2 - 1) {
+                // Full-line stores: the 4 lanes of a row hold 64 B of it per column pair, i.e. HALF a 128-B line per store instruction, the
+                // other half arriving a step later.  Lanes mq and mq ^ 8 swap one of their two 16-B pieces (four DPP row_ror:8 moves), after
+                // which a store instruction covers 8 rows x 128 B: every line leaves the CU complete, in one instruction.
+                const bool up = mq >= 8;
+                // bank-masked DPP moves write only the lanes that receive: lanes 8-15 of a row take their partner's jp = 1 piece into x,
+                // lanes 0-7 their partner's jp = 0 piece into y (eight moves per row block, no selects)
+                u32x4 x = opair[0], y = opair[1];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    x[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)x[r], (int)opair[1][r], 0x128, 0xf, 0xc, false);
+                    y[r] = (uint32_t)__builtin_amdgcn_update_dpp((int)y[r], (int)opair[0][r], 0x128, 0xf, 0x3, false);
+                }
+                const int cbs = col_of(up ? 1 : 0);
+                const int rx = m_base + i * 16 + (mq & 7), ry = rx + 8;
+                u32x4* dx = reinterpret_cast<u32x4*>(p.out + (uint32_t)rx * (uint32_t)p.ldc + n0 + cbs);
+                u32x4* dy = reinterpret_cast<u32x4*>(p.out + (uint32_t)ry * (uint32_t)p.ldc + n0 + cbs);
+#ifdef ARX_DEV_VARIANTS
+                if (p.dev_store == 3) { asm volatile("" :: "v"(x), "v"(y), "v"(dx), "v"(dy)); if (p.ldc == 0x7fffffff) { *dx = x; *dy = y; } }
+                else if (p.dev_store == 1) {      // asm: hipcc merged half of the builtin's nt stores with the plain branch's and dropped the flag
+                    if (!CHECK || rx < M) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dx), "v"(x) : "memory");
+                    if (!CHECK || ry < M) asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dy), "v"(y) : "memory");
+                }
+                else
+#endif
+                { if (!CHECK || rx < M) *dx = x; if (!CHECK || ry < M) *dy = y; }
+              }
+            } else {
                 u32x4* dst = reinterpret_cast<u32x4*>(p.out + (uint32_t)row_of(i) * (uint32_t)p.ldc + n0 + cb);
 #ifdef ARX_DEV_VARIANTS
-                if (p.dev_store == 1) __builtin_nontemporal_store(o, dst);
+                if (p.dev_store == 3) { asm volatile("" :: "v"(o), "v"(dst)); if (p.ldc == 0x7fffffff) *dst = o; }      // probe: epilogue math without its stores
+                else if (p.dev_store == 1) __builtin_nontemporal_store(o, dst);
                 else if (p.dev_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(o) : "memory");
                 else
 #endif

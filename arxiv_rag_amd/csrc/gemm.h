@@ -228,6 +228,7 @@ struct EpiParams {
 #ifdef ARX_DEV_VARIANTS
     int dev_store = 0;              // dev A/B: 0 plain stores, 1 non-temporal, 2 sc1 (write-through, line dropped from L2)
     int dev_bw = 0;                 // dev A/B: band width of the tile walk in n-tiles (0 = TileWalk's own choice)
+    int dev_stagger = 0, dev_slots = 8;   // dev A/B (persistent kernel): block b starts (b / 8 % dev_slots) * dev_stagger cycles late
 #endif
 #ifdef ARX_STAMP
     unsigned long long* stamps = nullptr;   // dev build only: [tiles][4] s_memtime at start / loop entry / loop exit / end (wave 0)
@@ -319,7 +320,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else static_assert(N < 0, "add the vmcnt literal");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int SLOTS, int OPT = 0>

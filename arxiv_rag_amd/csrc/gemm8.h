@@ -62,11 +62,22 @@ struct TileWalk {
         return true;
     }
 };
-template <typename T, int KROT>
+// PERM: the 32 W rows (output columns) of a B half-tile slice are PLACED in LDS so that MFMA block j (0/1) of the slice holds the columns
+// 8g + 4j + [0,4), g = 0..3, instead of 16j + [0,16): a lane's four accumulator values of block 0 and of block 1 are then EIGHT CONSECUTIVE
+// output columns (16 B of bf16) and the epilogue needs no cross-lane exchange (epi3.h).  Only the source row of each DMA piece changes; the
+// LDS image, the swizzle and every fragment read are the same.
+__device__ __forceinline__ int b_slice_col(int rho) { return ((rho & 15) >> 2) * 8 + (rho >> 4) * 4 + (rho & 3); }
+
+template <typename T, int KROT, bool PERM = false>
 struct Gemm8Phase {
     static constexpr int BM = 256, BN = 256, NT = 512, MI = 8, NI = 4;
     static constexpr int HALF_BYTES = 128 * 128, BUF_BYTES = 4 * HALF_BYTES, STAGE_OFF = 2 * BUF_BYTES;
+#ifdef ARX_STAMP
+    static constexpr int KT_STAMP_OFF = STAGE_OFF + 2 * EpiStage::BYTES;    // dev build: 2 groups x 16 k-tile start stamps
+    static constexpr int SMEM_BYTES = KT_STAMP_OFF + 256;
+#else
     static constexpr int SMEM_BYTES = STAGE_OFF + 2 * EpiStage::BYTES;      // k-tile buffers + two epilogue-vector stages
+#endif
     using vec = typename Mfma<T>::vec;
 
     static __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
@@ -100,7 +111,7 @@ struct Gemm8Phase {
                 int gm = m0 + (r >> 6) * 128 + h * 64 + (r & 63);
                 gm = gm < M ? gm : M - 1;
                 aoff[h][it] = ((uint32_t)gm * (uint32_t)lda + c * 8) * 2u;      // BYTE offsets: the voffset operand of buffer_load ... lds
-                int gn = n0 + (r >> 5) * 64 + h * 32 + (r & 31);
+                int gn = n0 + (r >> 5) * 64 + h * 32 + (PERM ? b_slice_col(r & 31) : (r & 31));
                 gn = gn < N ? gn : N - 1;
                 boff[h][it] = ((uint32_t)gn * (uint32_t)ldw + c * 8) * 2u;
             }
@@ -218,7 +229,7 @@ template <int MODE, int KROT = 0>
 __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                            const bf16_t* __restrict__ W, int64_t ldw,
                                                            int M, int N, int K, int tiles_m, int tiles_n, EpiParams ep) {
-    using ML = Gemm8Phase<bf16_t, KROT>;
+    using ML = Gemm8Phase<bf16_t, KROT, true>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef ARX_DEV_VARIANTS
     const TileWalk walk(tiles_m, tiles_n, K, ep.dev_bw);
@@ -245,10 +256,13 @@ __global__ __launch_bounds__(512) void gemm_8phase_kernel(const bf16_t* __restri
 #endif
     epilogue_store_v3<MODE>(acc, ep, m0, n0, wid >> 2, wid & 3, lane, M, N, smem + ML::STAGE_OFF);
 #ifdef ARX_STAMP
+    const unsigned long long ts3 = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every store of the epilogue acknowledged
+    const unsigned long long ts4 = __builtin_readcyclecounter();
     if (ep.stamps && (threadIdx.x == 0 || threadIdx.x == 256)) {
-        unsigned long long* o = ep.stamps + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 4;
-        o[0] = ts0; o[1] = ts2; o[2] = __builtin_readcyclecounter();
-        o[3] = ts1;
+        unsigned long long* o = ep.stamps + ((size_t)blockIdx.x * 2 + (threadIdx.x >> 8)) * 32;
+        o[0] = ts0; o[1] = ts2; o[2] = ts3;
+        o[3] = ts1; o[4] = ts4; o[5] = 0; o[6] = 0; o[7] = 0;
     }
 #endif
 }
@@ -292,7 +306,7 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int cid = it * 512 + tid, r = cid >> 3, c = (cid & 7) ^ ((r >> 1) & 7);
-            int gn = n0 + (r >> 5) * 64 + g * 32 + (r & 31);
+            int gn = n0 + (r >> 5) * 64 + g * 32 + (Pol::PERMUTE_B ? b_slice_col(r & 31) : (r & 31));
             gn = gn < N ? gn : N - 1;
             if constexpr (Pol::REBASE_W) gn -= n0;                          // relative to the tile's descriptor base
             boff[g][it] = ((uint32_t)gn * (uint32_t)ldw + c * 8) * 2u;
@@ -357,7 +371,13 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
     pol.stage_issue(m0, n0, smem + ML::STAGE_OFF, wid, lane);
     issue_b(0, kcol(0, ko), 0); issue_a(0, kcol(0, ko), 0); issue_b(1, kcol(0, ko), 0); issue_a(1, kcol(0, ko), 0);
     issue_b(0, kcol(1, ko), 1); issue_a(0, kcol(1, ko), 1); issue_b(1, kcol(1, ko), 1);
+#ifdef ARX_EARLY_A1
+    issue_a(1, kcol(1, ko), 1);
+    wait_vmcnt<8>();
+    bool relaxed = false;                                        // this tile's first counted wait may step over the previous epilogue's VMEM ops
+#else
     wait_vmcnt<6>();
+#endif
     ML::bar();
     if (wr == 1) ML::bar();
 
@@ -375,6 +395,7 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
             for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifdef ARX_STAMP
         const unsigned long long pts0 = __builtin_readcyclecounter();
+        unsigned long long wst[4] = {0, 0, 0, 0};                // k-tile 0 / 1: time around the counted wait
 #endif
 
         for (int kt = 0; kt < nk; ++kt) {
@@ -384,6 +405,9 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
             const bool go1 = more1 || has_next, go2 = more2 || has_next;
             const int kc1 = more1 ? kcol(kt + 1, ko) : kcol(0, kon);
             const int kc2 = more2 ? kcol(kt + 2, ko) : kcol(kt + 2 - nk, kon);
+#ifdef ARX_STAMP
+            if (kt < 16 && (tid & 255) == 0) *reinterpret_cast<volatile unsigned long long*>(smem + ML::KT_STAMP_OFF + (tid >> 8) * 128 + kt * 8) = __builtin_readcyclecounter();
+#endif
             // ---- phase 1
             read_b(cur, 0, wf0);
             __builtin_amdgcn_sched_barrier(0);
@@ -394,7 +418,11 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
                 if (edge) { asm volatile("" : "+s"(m0n)); set_aoff(1, m0n); }      // clamped rows: recompute (last tile row only)
                 else { aoff[1][0] += d_a; aoff[1][1] += d_a; }
             }
+#ifdef ARX_EARLY_A1
+            if (go1 && kt != 0) issue_a(1, kc1, b ^ 1);          // k-tile 1's A1 pieces were issued ahead of the previous epilogue (or by the prologue)
+#else
             if (go1) issue_a(1, kc1, b ^ 1);
+#endif
             asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
             ML::bar();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -426,8 +454,25 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
             quad(1, 1, wf1);
             ML::bar();
             // ---- phase 4
+#ifdef ARX_STAMP
+#ifdef ARX_STAMP_WAITS
+            if (kt == 0) wst[0] = __builtin_readcyclecounter(); else if (kt == 1) wst[2] = __builtin_readcyclecounter();
+#endif
+#endif
+#ifdef ARX_EARLY_A1
+            // vmcnt retires in issue order: the tile's first counted wait would otherwise wait for every store of the previous epilogue
+            // (younger than k-tile 1's pieces, older than this k-tile's three).  Stepping over exactly Pol::EPI_VMEM of them is safe only
+            // when the epilogue issued at least that many (interior tiles; `relaxed`).
+            if (go2) { issue_b(1, kc2, b); if (kt == 0 && relaxed) wait_vmcnt<6 + Pol::EPI_VMEM>(); else wait_vmcnt<6>(); }
+#else
             if (go2) { issue_b(1, kc2, b); wait_vmcnt<6>(); }
+#endif
             else wait_vmcnt<0>();
+#ifdef ARX_STAMP
+#ifdef ARX_STAMP_WAITS
+            if (kt == 0) wst[1] = __builtin_readcyclecounter(); else if (kt == 1) wst[3] = __builtin_readcyclecounter();
+#endif
+#endif
             ML::bar();
             quad(1, 0, wf0);
             if (go1 || wr == 0) ML::bar();
@@ -439,10 +484,14 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
 #ifdef ARX_STAMP
         const unsigned long long pts1 = __builtin_readcyclecounter();
 #endif
+#ifdef ARX_EARLY_A1
+        if (has_next) issue_a(1, kcol(1, kon), 1);               // the stream's eighth half-tile: OLDER than the epilogue's stores
+        relaxed = Pol::EPI_VMEM > 0 && (m0 + wr * 128 + 128 <= M) && (n0 + wc * 64 + 64 <= N);
+#endif
         pol.epilogue(acc, m0, n0, wr, wc, lane, smem + ML::STAGE_OFF + sbuf * EpiStage::BYTES);
         if (has_next && wr == 1) ML::bar();
 #ifdef ARX_STAMP
-        pol.stamp(orig, tid, pts0, pts1);
+        pol.stamp(orig, tid, pts0, pts1, wst, smem + ML::KT_STAMP_OFF);
 #endif
         if (!has_next) break;
         orig = onext; m0 = m0n; n0 = n0n; ko = kon; sbuf ^= 1;
@@ -453,6 +502,10 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
 template <int MODE, int KROT>
 struct EncoderTilePolicy {
     static constexpr bool REBASE_W = false;
+    static constexpr bool PERMUTE_B = true;                      // epilogue v3 expects the permuted column placement (Gemm8Phase PERM)
+    // vector-memory instructions a wave's INTERIOR epilogue issues (16 output stores; residual modes 16 loads more; statistics 16 stores more)
+    static constexpr int EPI_VMEM = 16 + ((MODE == EPI_BIAS_RESID || MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS) ? 16 : 0)
+                                       + ((MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS) ? 16 : 0);
     TileWalk walk;
     const EpiParams& ep;
     int M, N, nk;
@@ -470,10 +523,13 @@ struct EncoderTilePolicy {
         epilogue_store_v3<MODE, (MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS) ? 4 : 8>(acc, ep, m0, n0, wr, wc, lane, M, N, stage);
     }
 #ifdef ARX_STAMP
-    __device__ __forceinline__ void stamp(int orig, int tid, unsigned long long pts0, unsigned long long pts1) const {
+    __device__ __forceinline__ void stamp(int orig, int tid, unsigned long long pts0, unsigned long long pts1, const unsigned long long (&wst)[4], const char* kts) const {
         if (ep.stamps && (tid == 0 || tid == 256)) {
-            unsigned long long* o = ep.stamps + ((size_t)orig * 2 + (tid >> 8)) * 4;
+            unsigned long long* o = ep.stamps + ((size_t)orig * 2 + (tid >> 8)) * 32;
             o[0] = pts0; o[1] = pts1; o[2] = __builtin_readcyclecounter(); o[3] = pts0;
+            o[4] = wst[0]; o[5] = wst[1]; o[6] = wst[2]; o[7] = wst[3];
+#pragma unroll 1
+            for (int k = 0; k < 16; ++k) o[8 + k] = *reinterpret_cast<const volatile unsigned long long*>(kts + (tid >> 8) * 128 + k * 8);
         }
     }
 #endif
@@ -490,5 +546,11 @@ __global__ __launch_bounds__(512) void gemm_8phase_persistent_kernel(const bf16_
     const TileWalk walk(tiles_m, tiles_n, K);
 #endif
     const EncoderTilePolicy<MODE, KROT> pol{walk, ep, M, N, K >> 6};
+#ifdef ARX_DEV_VARIANTS
+    if (ep.dev_stagger > 0) {        // probe: CUs of an XCD out of phase with one another
+        const long long wait = (long long)((blockIdx.x >> 3) % ep.dev_slots) * ep.dev_stagger, t0 = clock64();
+        while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     gemm8_persistent_body<bf16_t>(A, lda, W, ldw, M, N, K, pol, smem);
 }

@@ -350,6 +350,8 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
 template <bool I8>
 struct SearchTilePolicy {
     static constexpr bool REBASE_W = true;
+    static constexpr int EPI_VMEM = 0;
+    static constexpr bool PERMUTE_B = false;                     // a group's arg-max row is a position inside the tile: corpus rows stay in order
     int tiles_q, tiles_n, nq, D;
     int64_t n_rows, ldg;
     float* gmax;
@@ -377,7 +379,7 @@ struct SearchTilePolicy {
             groupmax_epilogue_f16<8, 4>(acc, gmax + g * ldg, m0 + wr * 128, nq, lane);
     }
 #ifdef ARX_STAMP
-    __device__ __forceinline__ void stamp(int, int, unsigned long long, unsigned long long) const {}
+    __device__ __forceinline__ void stamp(int, int, unsigned long long, unsigned long long, const unsigned long long (&)[4], const char*) const {}
 #endif
 };
 
