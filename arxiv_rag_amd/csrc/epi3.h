@@ -39,15 +39,25 @@ __device__ __forceinline__ void epi_stage_issue(const EpiParams& p, int m0, int 
     if (src) __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + l * 4), (lds_void_t*)(stage + w * 1024), 16, 0, 0);
 }
 
-// Full-line stores (below) pay eight DPP moves per row block: worth it everywhere (same-box A/B in situ: QKV -2.4 %, O-projection -2.8 %,
-// FFN-2 -0.5 % against 64-B half-line stores) except in the GELU epilogues, which are bound by their VALU work (FFN-1 +6 %).
+// Full-line, non-temporal output stores (profiles/r03/gemm_epilogue_store_probe.md).  The 4 lanes of an output row hold 64 B of it per column
+// pair: half a 128-B line per store instruction, the other half a step later.  Lanes mq and mq ^ 8 exchange one 16-B piece each (eight
+// bank-masked DPP moves per row block), after which an instruction covers 8 rows x 128 B.  With complete lines the stores can be `nt`:
+// the output stream (1.2-1.6 GB per launch through 32 MB of L2) then stops evicting operand lines (+50 % fabric reads with plain stores)
+// and leaves fewer dirty lines for the next kernel to drain; `nt` on HALF lines is slower than plain stores (the halves leave the L2
+// separately: +44 % fabric writes).  Same-box in-situ A/B, chunks/s: half-line plain 21 060 (placement only) · full-line plain except GELU
+// 21 580 / 21 730 · + nt on those 21 870 · full-line nt everywhere 21 965.  ARX_FL_NONE / ARX_NT_NONE rebuild the older forms.
 template <int MODE> struct EpiFullLine {
-#if defined(ARX_FL_ALL)
-    static constexpr bool value = true;
-#elif defined(ARX_FL_NONE)
+#if defined(ARX_FL_NONE)
     static constexpr bool value = false;
 #else
-    static constexpr bool value = !(MODE == EPI_BIAS_GELU || MODE == EPI_LN_BIAS_GELU);
+    static constexpr bool value = true;
+#endif
+};
+template <int MODE> struct EpiStoreNT {
+#if defined(ARX_NT_NONE)
+    static constexpr bool value = false;
+#else
+    static constexpr bool value = EpiFullLine<MODE>::value;
 #endif
 };
 
@@ -138,9 +148,6 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
             if constexpr (FL) {
               opair[jp] = o;
               if (jp == NI / 2 - 1) {
-                // Full-line stores: the 4 lanes of a row hold 64 B of it per column pair, i.e. HALF a 128-B line per store instruction, the
-                // other half arriving a step later.  Lanes mq and mq ^ 8 swap one of their two 16-B pieces (four DPP row_ror:8 moves), after
-                // which a store instruction covers 8 rows x 128 B: every line leaves the CU complete, in one instruction.
                 const bool up = mq >= 8;
                 // bank-masked DPP moves write only the lanes that receive: lanes 8-15 of a row take their partner's jp = 1 piece into x,
                 // lanes 0-7 their partner's jp = 0 piece into y (eight moves per row block, no selects)
@@ -162,7 +169,10 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
                 }
                 else
 #endif
-                { if (!CHECK || rx < M) *dx = x; if (!CHECK || ry < M) *dy = y; }
+                if constexpr (EpiStoreNT<MODE>::value) {
+                    if (!CHECK || rx < M) __builtin_nontemporal_store(x, dx);
+                    if (!CHECK || ry < M) __builtin_nontemporal_store(y, dy);
+                } else { if (!CHECK || rx < M) *dx = x; if (!CHECK || ry < M) *dy = y; }
               }
             } else {
                 u32x4* dst = reinterpret_cast<u32x4*>(p.out + (uint32_t)row_of(i) * (uint32_t)p.ldc + n0 + cb);
@@ -172,7 +182,8 @@ __device__ __forceinline__ void epilogue_store_v3_impl(const f32x4 (&acc)[4][8],
                 else if (p.dev_store == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(o) : "memory");
                 else
 #endif
-                    *dst = o;
+                if constexpr (EpiStoreNT<MODE>::value) __builtin_nontemporal_store(o, dst);
+                else *dst = o;
             }
             if constexpr (STATS) {
                 // statistics of the bf16-ROUNDED values (what the consumers will read back)

@@ -371,13 +371,7 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
     pol.stage_issue(m0, n0, smem + ML::STAGE_OFF, wid, lane);
     issue_b(0, kcol(0, ko), 0); issue_a(0, kcol(0, ko), 0); issue_b(1, kcol(0, ko), 0); issue_a(1, kcol(0, ko), 0);
     issue_b(0, kcol(1, ko), 1); issue_a(0, kcol(1, ko), 1); issue_b(1, kcol(1, ko), 1);
-#ifdef ARX_EARLY_A1
-    issue_a(1, kcol(1, ko), 1);
-    wait_vmcnt<8>();
-    bool relaxed = false;                                        // this tile's first counted wait may step over the previous epilogue's VMEM ops
-#else
     wait_vmcnt<6>();
-#endif
     ML::bar();
     if (wr == 1) ML::bar();
 
@@ -418,11 +412,7 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
                 if (edge) { asm volatile("" : "+s"(m0n)); set_aoff(1, m0n); }      // clamped rows: recompute (last tile row only)
                 else { aoff[1][0] += d_a; aoff[1][1] += d_a; }
             }
-#ifdef ARX_EARLY_A1
-            if (go1 && kt != 0) issue_a(1, kc1, b ^ 1);          // k-tile 1's A1 pieces were issued ahead of the previous epilogue (or by the prologue)
-#else
             if (go1) issue_a(1, kc1, b ^ 1);
-#endif
             asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
             ML::bar();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -459,14 +449,7 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
             if (kt == 0) wst[0] = __builtin_readcyclecounter(); else if (kt == 1) wst[2] = __builtin_readcyclecounter();
 #endif
 #endif
-#ifdef ARX_EARLY_A1
-            // vmcnt retires in issue order: the tile's first counted wait would otherwise wait for every store of the previous epilogue
-            // (younger than k-tile 1's pieces, older than this k-tile's three).  Stepping over exactly Pol::EPI_VMEM of them is safe only
-            // when the epilogue issued at least that many (interior tiles; `relaxed`).
-            if (go2) { issue_b(1, kc2, b); if (kt == 0 && relaxed) wait_vmcnt<6 + Pol::EPI_VMEM>(); else wait_vmcnt<6>(); }
-#else
             if (go2) { issue_b(1, kc2, b); wait_vmcnt<6>(); }
-#endif
             else wait_vmcnt<0>();
 #ifdef ARX_STAMP
 #ifdef ARX_STAMP_WAITS
@@ -484,10 +467,6 @@ __device__ __forceinline__ void gemm8_persistent_body(const T* __restrict__ A, i
 #ifdef ARX_STAMP
         const unsigned long long pts1 = __builtin_readcyclecounter();
 #endif
-#ifdef ARX_EARLY_A1
-        if (has_next) issue_a(1, kcol(1, kon), 1);               // the stream's eighth half-tile: OLDER than the epilogue's stores
-        relaxed = Pol::EPI_VMEM > 0 && (m0 + wr * 128 + 128 <= M) && (n0 + wc * 64 + 64 <= N);
-#endif
         pol.epilogue(acc, m0, n0, wr, wc, lane, smem + ML::STAGE_OFF + sbuf * EpiStage::BYTES);
         if (has_next && wr == 1) ML::bar();
 #ifdef ARX_STAMP
@@ -503,9 +482,6 @@ template <int MODE, int KROT>
 struct EncoderTilePolicy {
     static constexpr bool REBASE_W = false;
     static constexpr bool PERMUTE_B = true;                      // epilogue v3 expects the permuted column placement (Gemm8Phase PERM)
-    // vector-memory instructions a wave's INTERIOR epilogue issues (16 output stores; residual modes 16 loads more; statistics 16 stores more)
-    static constexpr int EPI_VMEM = 16 + ((MODE == EPI_BIAS_RESID || MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS) ? 16 : 0)
-                                       + ((MODE == EPI_RESID_STATS || MODE == EPI_LNRESID_STATS) ? 16 : 0);
     TileWalk walk;
     const EpiParams& ep;
     int M, N, nk;

@@ -350,7 +350,6 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
 template <bool I8>
 struct SearchTilePolicy {
     static constexpr bool REBASE_W = true;
-    static constexpr int EPI_VMEM = 0;
     static constexpr bool PERMUTE_B = false;                     // a group's arg-max row is a position inside the tile: corpus rows stay in order
     int tiles_q, tiles_n, nq, D;
     int64_t n_rows, ldg;
