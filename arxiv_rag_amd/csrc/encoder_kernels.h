@@ -707,17 +707,34 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void attention_tr_kernel(const uin
     }
 
     const float inv = 1.0f / l_tot;
-    if (q < L) {
-        uint16_t* orow = ctx + (int64_t)(t0 + q) * H + h * DH;
+    // Output row of a query: lanes (q, hh = 0 / 1) hold interleaved 8-B pieces of it (d = 8 g4 + 4 hh + [0, 4) per 32-wide block).  Four
+    // v_permlane32_swap per block regroup them — the lower lane keeps d 0..15, the upper lane d 16..31 — so that a lane stores 16 B at a
+    // time: four dwordx4 stores per lane instead of eight dwordx2 (the store tail of a block is issue-bound: half the instructions).
+    u32x4 pc[DB][2];
 #pragma unroll
-        for (int d = 0; d < DB; ++d)
+    for (int d = 0; d < DB; ++d) {
+        uint32_t w[4][2];
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                u32x2 w2;
-                w2[0] = pack_bf16x2(o[d][g4 * 4 + 0] * inv, o[d][g4 * 4 + 1] * inv);
-                w2[1] = pack_bf16x2(o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv);
-                *reinterpret_cast<u32x2*>(orow + d * 32 + 8 * g4 + 4 * hh) = w2;
+        for (int g4 = 0; g4 < 4; ++g4) {
+            w[g4][0] = pack_bf16x2(o[d][g4 * 4 + 0] * inv, o[d][g4 * 4 + 1] * inv);
+            w[g4][1] = pack_bf16x2(o[d][g4 * 4 + 2] * inv, o[d][g4 * 4 + 3] * inv);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                // swap(upper half of w[g], lower half of w[g + 2]): lower lanes end with {own g, partner's g}, upper lanes with {partner's g + 2, own g + 2}
+                const auto sw = __builtin_amdgcn_permlane32_swap(w[g][k], w[g + 2][k], false, false);
+                pc[d][g][k] = sw[0]; pc[d][g][2 + k] = sw[1];
             }
+    }
+    if (q < L) {
+        uint16_t* orow = ctx + (int64_t)(t0 + q) * H + h * DH + 16 * hh;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+            *reinterpret_cast<u32x4*>(orow + d * 32) = pc[d][0];            // plain stores: `nt` on these 16-B pieces gives the gain back (0.397 ms)
+            *reinterpret_cast<u32x4*>(orow + d * 32 + 8) = pc[d][1];
+        }
     }
 #ifdef ARX_DEV_VARIANTS
     if (dev_stamps && (threadIdx.x & 63) == 0) atomicMax(&dev_stamps[4 * lin + 2], (unsigned long long)wall_clock64());
