@@ -19,7 +19,8 @@ out = Path(sys.argv[1] if len(sys.argv) > 1 else ROOT / "gpurun_out" / "epi_prob
 st = torch.cuda.current_stream().cuda_stream
 M = 262144
 shapes = [("qkv", 2304, 768, 0), ("oproj", 768, 768, 2), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 2)]
-cfgs = [("base", 9, None), ("nostore", 309, None), ("stg5500x8", 9, "5500,8"), ("pertile", 8, None), ("pertile_nostore", 308, None)]
+if os.environ.get("EPI_PROBE_SHAPES"): shapes = [s for s in shapes if s[0] in os.environ["EPI_PROBE_SHAPES"].split(",")]
+cfgs = [("base", 9, None), ("nostore", 309, None), ("noresid", 409, None), ("pertile", 8, None), ("pertile_nostore", 308, None), ("pertile_noresid", 408, None)]
 stamped = bool(lib.arx_build_info() & 2) if hasattr(lib, "arx_build_info") else False
 g = torch.Generator(device=dev); g.manual_seed(0)
 
@@ -52,7 +53,7 @@ for name, N, K, mode in shapes:
     with open(out / "timing.jsonl", "a") as f: f.write(json.dumps(row) + "\n")
     if os.environ.get("EPI_PROBE_STAMPS") == "1":
         os.environ["ARX_STAMP_DUMP"] = "1"
-        for cn, v, stg in (("base", 9, None), ("nostore", 309, None), ("pertile", 8, None)):
+        for cn, v, stg in (("base", 9, None), ("nostore", 309, None), ("noresid", 409, None), ("pertile", 8, None), ("pertile_noresid", 408, None)):
             os.environ["ARX_STAMP_FILE"] = str(out / f"stamps_{name}_{cn}.bin")
             run(v, stg, A, W, b, R, C, mode)
             torch.cuda.synchronize()
