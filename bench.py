@@ -603,9 +603,22 @@ def main():
                 if "ms_per_batch_pipelined" in e:
                     e["batch_frac_of_hbm_roofline_pipelined"] = round(((h8 - l8) * D * 2 / HBM_PEAK * 1e3) / e["ms_per_batch_pipelined"], 4)
                 r625[f"Qb={qb}"] = e
+            # the same slice behind the int8 first pass (half the bytes; identical exact rows): the batch against the SAME fp16-bytes roofline
+            sl8 = ShardIndex(shard_rows[l8:h8], idx_base=l8, prefilter="int8")
+            r625_8 = {}
+            for qb in (64, 256):
+                qb = min(qb, nq_all)
+                e = time_search(sl8, queries, qb, h8 - l8, D, int8_bytes=True, pipelined=True)
+                e["batch_frac_of_fp16_hbm_roofline"] = round(((h8 - l8) * D * 2 / HBM_PEAK * 1e3) / e["ms_per_batch"], 4)
+                if "ms_per_batch_pipelined" in e:
+                    e["batch_frac_of_fp16_hbm_roofline_pipelined"] = round(((h8 - l8) * D * 2 / HBM_PEAK * 1e3) / e["ms_per_batch_pipelined"], 4)
+                s16, i16 = sl.search(queries[:qb], 10)
+                s8, i8 = sl8.search(queries[:qb], 10)
+                e["rows_identical_to_fp16_pass"] = float((i16 == i8).all(dim=1).float().mean().item())
+                r625_8[f"Qb={qb}"] = e
             search["shard_625k"] = {"workload": f"rows [{l8}, {h8}) of the configs[3] corpus = one rank's slice of an 8-way cut, {D}-d, on one GPU",
-                                    "results": r625}
-            del sl
+                                    "results": r625, "int8_prefilter": r625_8}
+            del sl, sl8
         del sidx, shard_rows
         torch.cuda.empty_cache()
 
