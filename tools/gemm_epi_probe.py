@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Dev probe (library built with -DARX_DEV_VARIANTS [-DARX_STAMP], ARX_LIB pointing at it): what the persistent GEMM's epilogue
 costs and whether the CUs of the chip go through it in lockstep.
-  * same launch with the epilogue's stores skipped (variant + 300),
+  * same launch with the epilogue's stores skipped (variant + 300; a "residual loads skipped" arm existed while section 7 of
+    profiles/r03/gemm_epilogue_store_probe.md was measured),
   * blocks started out of phase (ARX_DEV_STAGGER=cycles,slots: block b waits (b / 8 % slots) * cycles),
   * with ARX_STAMP: raw per-tile stamps to gpurun_out/stamps_<shape>_<cfg>.bin ([tiles][2 groups][4] u64).
 usage: gemm_epi_probe.py [outdir]"""
@@ -20,7 +21,7 @@ st = torch.cuda.current_stream().cuda_stream
 M = 262144
 shapes = [("qkv", 2304, 768, 0), ("oproj", 768, 768, 2), ("fc1", 3072, 768, 1), ("fc2", 768, 3072, 2)]
 if os.environ.get("EPI_PROBE_SHAPES"): shapes = [s for s in shapes if s[0] in os.environ["EPI_PROBE_SHAPES"].split(",")]
-cfgs = [("base", 9, None), ("nostore", 309, None), ("noresid", 409, None), ("pertile", 8, None), ("pertile_nostore", 308, None), ("pertile_noresid", 408, None)]
+cfgs = [("base", 9, None), ("nostore", 309, None), ("stg5500x8", 9, "5500,8"), ("pertile", 8, None), ("pertile_nostore", 308, None)]
 stamped = bool(lib.arx_build_info() & 2) if hasattr(lib, "arx_build_info") else False
 g = torch.Generator(device=dev); g.manual_seed(0)
 
@@ -53,7 +54,7 @@ for name, N, K, mode in shapes:
     with open(out / "timing.jsonl", "a") as f: f.write(json.dumps(row) + "\n")
     if os.environ.get("EPI_PROBE_STAMPS") == "1":
         os.environ["ARX_STAMP_DUMP"] = "1"
-        for cn, v, stg in (("base", 9, None), ("nostore", 309, None), ("noresid", 409, None), ("pertile", 8, None), ("pertile_noresid", 408, None)):
+        for cn, v, stg in (("base", 9, None), ("nostore", 309, None), ("pertile", 8, None)):
             os.environ["ARX_STAMP_FILE"] = str(out / f"stamps_{name}_{cn}.bin")
             run(v, stg, A, W, b, R, C, mode)
             torch.cuda.synchronize()
