@@ -837,6 +837,34 @@ def test_linear_layer_variants_vs_fp32(hip, variant):
             assert err < 0.02 * max(1.0, want.abs().max().item()), (variant, M, N, K, mode, err)
 
 
+@pytest.mark.parametrize("variant", [8, 9])
+def test_gemm_full_line_stores_stay_inside_the_output(hip, variant):
+    """Epilogue v3 writes complete 128-B lines: lanes mq and mq ^ 8 exchange 16-B pieces, so a lane stores rows it did not compute (row
+    mq + 8 of its block, or mq - 8).  With ragged M the partner's row may not exist, and with N % 256 == 128 half of the last n-tile's waves
+    have no columns: nothing may be written past row M (guard rows behind the output keep their pattern) or past column N (it would land
+    in the next row: every value is compared), for every row count around the 8- and 16-row boundaries of a row block."""
+    lib = hip.load()
+    g = torch.Generator(device="cuda"); g.manual_seed(100 + variant)
+    st = torch.cuda.current_stream().cuda_stream
+    GUARD = 24
+    for N, K in ((256, 128), (384, 128), (768, 256)):
+        W = (torch.randn((N, K), device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+        b = torch.randn((N,), device="cuda", generator=g)
+        for M in (1, 7, 8, 9, 15, 17, 121, 129, 136, 255, 257, 263, 264, 391):
+            A = torch.randn((M, K), device="cuda", generator=g).to(torch.bfloat16)
+            R = torch.randn((M, N), device="cuda", generator=g).to(torch.bfloat16)
+            for mode in (0, 1, 2):
+                buf = torch.full((M + GUARD, N), -7.0, device="cuda", dtype=torch.bfloat16)
+                hip.check(lib.arx_gemm_bf16(A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr(), buf.data_ptr(), M, N, K, mode,
+                                            variant, st), "arx_gemm_bf16")
+                torch.cuda.synchronize()
+                assert (buf[M:] == -7.0).all().item(), (variant, M, N, K, mode, "write past row M")
+                want = A.float() @ W.float().T + b
+                want = torch.nn.functional.gelu(want) if mode == 1 else (want + R.float() if mode == 2 else want)
+                err = (buf[:M].float() - want).abs().max().item()
+                assert err < 0.02 * max(1.0, want.abs().max().item()), (variant, M, N, K, mode, err)
+
+
 def test_persistent_gemm_bitwise_equals_per_tile_kernel(hip):
     """The persistent form of the 4-phase GEMM (prefetch stream running through tile boundaries, several tiles per block,
     a ragged last tile row) must reproduce the per-tile kernel bit for bit: same k order, same epilogue."""
