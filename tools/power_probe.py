@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev probe: run one GEMM shape/variant in a loop for a few seconds while sampling `rocm-smi` clocks and power
-(is the kernel power-limited?).  usage: power_probe.py <variant> [shape]"""
+(is the kernel power-limited?).  usage: [POWER_PROBE_ZERO=1] power_probe.py <variant> [shape]"""
 import subprocess, sys, threading, time, re
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -11,6 +11,9 @@ v = int(sys.argv[1]); shape = sys.argv[2] if len(sys.argv) > 2 else "qkv"
 N, K, mode = {"qkv": (2304, 768, 0), "fc1": (3072, 768, 1), "fc2": (768, 3072, 2)}[shape]
 M = 262144
 A = torch.randn((M, K), device=dev).to(torch.bfloat16); W = (torch.randn((N, K), device=dev) * 0.03).to(torch.bfloat16)
+import os
+if os.environ.get("POWER_PROBE_ZERO") == "1":      # zero operands: the same instruction stream with (almost) no data toggling
+    A.zero_(); W.zero_()
 b = torch.randn((N,), device=dev); R = torch.randn((M, N), device=dev).to(torch.bfloat16); C = torch.empty((M, N), device=dev, dtype=torch.bfloat16)
 samples = []; stop = False
 def sampler():
