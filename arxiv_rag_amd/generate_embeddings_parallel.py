@@ -181,7 +181,7 @@ def load_chunks_for_rank(output_dir: Path, min_quality: float, num_workers: Opti
         import torch.distributed as dist
         def gather_counts(x):                                          # noqa: E306
             out: List = [None] * world
-            dist.all_gather_object(out, x)
+            dist.all_gather_object(out, x, group=host_group())
             return out
     counts: List[int] = [n for part in gather_counts(counts_local) for n in part]
     assert len(counts) == len(files), "ranks disagree on the file list"
@@ -321,6 +321,44 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized()) else None
 
 
+_host_pg = None
+
+
+def init_distributed():
+    """Bring up this rank's process group (one process per GPU; the reference's counterpart is the `mp.Pool` of GEN:197-217).
+    The device is BOUND before the group exists: RCCL stages object collectives on `torch.cuda.current_device()`, which is cuda:0 in
+    every rank until someone says otherwise — the first collective of the run (`load_chunks_for_rank`'s count exchange) runs before
+    the model is loaded, and a communicator built with every rank on GPU 0 fails with "Duplicate GPU detected" or hangs
+    (ADVICE r3).  `device_id` also makes the communicator eager, so a mis-launch fails here and not in the middle of the load."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return
+    if torch.cuda.is_available():
+        local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+        n_dev = torch.cuda.device_count()
+        if local_rank >= n_dev:
+            raise RuntimeError(f"LOCAL_RANK={local_rank} but only {n_dev} GPU(s) visible: launch one rank per GPU")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group("gloo")
+
+
+def host_group():
+    """Process group for the HOST-side object exchanges of an N-rank run (per-file chunk counts, metadata bookkeeping, chunk ids of
+    merged hits): gloo over TCP, so that pickled Python objects never pass through device memory and the loader does not depend on
+    the GPU at all.  The default group itself when that already is gloo (CPU runs / tests)."""
+    global _host_pg
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo":
+        return None
+    if _host_pg is None:
+        _host_pg = dist.new_group(backend="gloo")
+    return _host_pg
+
+
 def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     per = (n_items + world - 1) // world
     lo = min(n_items, rank * per)
@@ -353,7 +391,7 @@ def generate_embeddings_parallel(chunks: List[Dict], model_name: str = "all-mpne
             print(f"Warning: Batch {idx} produced no embeddings")
     if dist and world > 1:
         gathered: List = [None] * world
-        dist.all_gather_object(gathered, (done, errors))
+        dist.all_gather_object(gathered, (done, errors), group=host_group())
         done, errors = {}, []
         for d, e in gathered:
             done.update(d); errors.extend(e)
@@ -644,7 +682,7 @@ def search_queries(model, chunks: List[Dict], shard: "ShardSink", queries: List[
              for j in np.unique(i) if chunk_base <= j < chunk_base + len(chunks)}
     if dist and world > 1:
         parts: List = [None] * world
-        dist.all_gather_object(parts, names)
+        dist.all_gather_object(parts, names, group=host_group())
         names = {k: v for part in parts for k, v in part.items()}
     results = []
     for qi, text in enumerate(queries):
@@ -699,11 +737,7 @@ def main(argv: Optional[Sequence[str]] = None, model_factory: Optional[Callable]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        if not dist.is_initialized():
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-            dist.init_process_group(backend)
+        init_distributed()
     cpu_count = effective_cpus()                                # usable by this job (cgroup quota), not the machine's logical CPUs
     print("=" * 80)
     print("PARALLEL EMBEDDING GENERATION - MI355X")
