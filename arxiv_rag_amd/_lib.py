@@ -31,6 +31,19 @@ class EncoderWeightsC(C.Structure):
                + [("layers", C.POINTER(LayerWeightsC))]
 
 
+class TopkOptionsC(C.Structure):
+    """arx_topk_options (include/arx.h): the per-call search policy; the library keeps none of its own."""
+    _fields_ = [("struct_bytes", C.c_int32), ("i8_max_queries", C.c_int32), ("max_row_norm", C.c_float), ("cu_limit", C.c_int32),
+                ("flags", C.c_int32), ("debug_tau_mult", C.c_float), ("debug_drop_best", C.c_int32)]
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.struct_bytes = C.sizeof(TopkOptionsC)
+
+
+TOPK_NO_PERSISTENT, TOPK_SCAN_ONLY, TOPK_TAIL_ONLY, TOPK_NO_SINGLE_ROW_TAIL = 1, 2, 4, 8
+
+
 EXPORTS = {
     # name: (restype, argtypes)
     "arx_version": (C.c_int32, []),
@@ -54,6 +67,14 @@ EXPORTS = {
     "arx_topk_build_i8": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "arx_topk_search_i8": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "arx_topk_workspace_bytes_i8": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "arx_topk_search_opt": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(TopkOptionsC), C.c_void_p]),
+    "arx_rows_max_norm_f16": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "arx_stream_create_cu_mask": (C.c_int32, [C.POINTER(C.c_uint32), C.c_int32, C.POINTER(C.c_void_p)]),
+    "arx_stream_destroy": (C.c_int32, [C.c_void_p]),
+    "arx_device_cu_count": (C.c_int32, []),
+    "arx_debug_cu_census": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "arx_topk_stats": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p]),
     "arx_topk_merge": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                    C.c_void_p]),
@@ -73,8 +94,8 @@ EXPORTS = {
     "arx_f32_to_bf16": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "arx_fill_unit_rows_f16": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_void_p]),
     "arx_fill_unit_rows_f16_at": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_void_p]),
-    "arx_topk_set_debug": (C.c_int32, [C.c_float, C.c_int32]),
-    "arx_topk_set_i8_max_queries": (C.c_int32, [C.c_int32]),
+    "arx_fill_clustered_rows_f16_at": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_int32, C.c_float, C.c_int32,
+                                                   C.c_float, C.c_void_p]),
     "arx_prof_enable": (C.c_int32, [C.c_int32]),
     "arx_prof_reset": (C.c_int32, []),
     "arx_prof_read": (C.c_int32, [C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),

@@ -23,6 +23,8 @@
 #define SUPER 16                      // groups per super-group in the selection pass
 #define SEL_SPLIT_WAVES 4            // waves per select block
 #define QBATCH_MAX 1024              // queries per internal pass (bounds the gmax workspace)
+#define AUX16_MAX_NQ 128              // fp16 pass: query batches up to this size write aux words and take the single-kernel tail
+#define TAIL_RS_MAX 16                // ... when the shard has at most TAIL_RS_MAX x 1024 super-groups (16.7 M rows)
 #define CNT_QCOUNT 2                 // layout of the int8 candidate pipeline's counter block: see collect_pairs_kernel
 #define CNT_QOVER (2 + QBATCH_MAX)
 #define CNT_INTS (2 + 2 * QBATCH_MAX)
@@ -89,6 +91,49 @@ __device__ __forceinline__ void groupmax_epilogue_f16(const f32x4 (&acc)[NI][MI]
         gm[i] = max_over_rows(mx);
     }
     store_query_row<MI, float>(gmax_row, gm, m_first, nq, lane);
+}
+
+// fp16 pass, small query batches (<= 128): beside the group maximum, the aux word (below) of the group — the position of the row that holds
+// the largest pass-A score and an upper bound on the pass-A score of every OTHER row of the group.  The tail kernel then reads ONE fp16 row
+// of a selected group (1.5 KB) instead of its 64 (98 KB) whenever that bound is below the query's threshold: on a 625 k-row shard the
+// rescoring of 12 x 64 rows per query — one CU pulling 1.2 MB — was 0.07 ms of a 0.26-ms batch (profiles/r03).  The arg-max travels in the
+// low 6 bits of each value's float image (63 ulp either way, covered by the 8e-6 inflation of the second bound); the group maximum
+// itself is taken from the untouched values, so the selection and the certificate see what they saw before.
+__device__ __forceinline__ uint32_t pack_aux(float ub2, int arg_row);
+template <int MI, int NI>
+__device__ __forceinline__ void groupmax_epilogue_f16_aux(const f32x4 (&acc)[NI][MI], float* __restrict__ gmax_row, uint32_t* __restrict__ aux_row,
+                                                          int m_first, int nq, int lane) {
+    float gm[MI];
+    uint32_t ga[MI];
+    const int lrow = (lane >> 4) * 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        float mx = -INFINITY, m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float u = acc[j][i][r];
+                mx = fmaxf(mx, u);
+                const float key = __uint_as_float((__float_as_uint(u) & ~63u) | (uint32_t)(j * 16 + r));
+                m2 = __builtin_amdgcn_fmed3f(m1, m2, key);
+                m1 = fmaxf(m1, key);
+            }
+        m1 = __uint_as_float(__float_as_uint(m1) | (uint32_t)lrow);
+        m2 = __uint_as_float(__float_as_uint(m2) | (uint32_t)lrow);
+        {
+            float a1, b1, a2, b2;
+            rows16(m1, a1, b1); rows16(m2, a2, b2);
+            m1 = fmaxf(a1, b1); m2 = fmaxf(fmaxf(a2, b2), fminf(a1, b1));
+            rows32(m1, a1, b1); rows32(m2, a2, b2);
+            m1 = fmaxf(a1, b1); m2 = fmaxf(fmaxf(a2, b2), fminf(a1, b1));
+        }
+        gm[i] = max_over_rows(mx);
+        const float b2 = m2 + fabsf(m2) * 8.0e-6f + 1e-12f;
+        ga[i] = pack_aux(b2, (int)(__float_as_uint(m1) & 63u));
+    }
+    store_query_row<MI, float>(gmax_row, gm, m_first, nq, lane);
+    store_query_row<MI, uint32_t>(aux_row, ga, m_first, nq, lane);
 }
 
 // aux word per (query, group), beside the group's upper bound: the SECOND largest row bound of the group rounded UP to 16 bits (bf16
@@ -199,8 +244,11 @@ template <int BM, bool GLDS>
 __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __restrict__ Q, int nq,
                                                                const f16_t* __restrict__ C, int64_t n_rows, int D,
                                                                int tiles_q, int tiles_n, float* __restrict__ gmax,
-                                                               int64_t ldg) {
+                                                               int64_t ldg, uint32_t* __restrict__ aux,
+                                                               unsigned long long* __restrict__ zero_stats) {
     using ML = GemmMainloop<f16_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;      // stagger + setprio as in the encoder GEMM
+    // (the certificate counters of a call whose tail has no select kernel start at zero here: the tail runs after this grid)
+    if (zero_stats && blockIdx.x == 0 && threadIdx.x < 2) zero_stats[threadIdx.x] = 0ull;
     static_assert(ML::TN == GROUP_ROWS, "one wave column = one group");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = xcd_remap(blockIdx.x, tiles_q * tiles_n);
@@ -224,7 +272,8 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
     const int wm = wid / 4, wn = wid % 4;
     if (wn * GROUP_ROWS >= rows_here) return;
     const int64_t g = (n0 >> 6) + wn;
-    groupmax_epilogue_f16<ML::MI, ML::NI>(acc, gmax + g * ldg, m0 + wm * ML::TM, nq, lane);
+    if (aux) groupmax_epilogue_f16_aux<ML::MI, ML::NI>(acc, gmax + g * ldg, aux + g * ldg, m0 + wm * ML::TM, nq, lane);
+    else groupmax_epilogue_f16<ML::MI, ML::NI>(acc, gmax + g * ldg, m0 + wm * ML::TM, nq, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -791,6 +840,284 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
     }
 }
 
+// ---- the tail of a SMALL query batch on the fp16 pass (<= 128 queries; pass A wrote the aux words): ONE kernel, one block per query ------
+// What the select kernel + rescore_kernel pair does (and still does for wide batches and the int8 pipeline), restructured around two facts
+// of the 625 k-row / 8-rank shape (profiles/r03: pass A 0.16 ms, select 0.011 + a launch boundary, rescore 0.068):
+//   * the selection reads ~10 k group maxima per query: the block reads its query's gmax column itself (strided 4-byte loads, L2 hits),
+//     16 groups per lane and step, instead of waiting for a second grid and its partial lists;
+//   * of the K x 64 rows it used to rescore, K matter: the row each selected group's maximum came from (aux: its position) — unless the
+//     group's SECOND best pass-A score (aux: an upper bound on it) reaches the provisional threshold, in which case the whole group is
+//     rescored as before.  One CU then pulls 18 KB per query instead of 1.2 MB.
+//   (1) every lane: maxima of its super-groups (16 consecutive groups) -> RS candidates per lane; wave top-(K+1); wave 0 merges: the K best
+//       super-groups + the best one left out
+//   (2) wave 0 expands them to K x 16 groups -> the K best groups + the best one left out           [as rescore_kernel]
+//   (3a) exact scores of the K arg-max rows (8 lanes per row); provisional s_k, thr' = s_k - tau; groups with ub2 >= thr' (or fewer
+//        than k rows so far) are EXPANDED: (3b) all their rows rescored
+//   (4) top-k of the candidates; (5) certificate exactly as rescore_kernel's: U bounds every row in a group that was not selected; rows of a
+//       selected, unexpanded group other than its arg-max row have pass-A score <= ub2 < thr' <= thr (s_k only grows as rows are added),
+//       so they are covered too.  The fallback (every unscored group with gmax >= thr) is the same code.
+template <int K, int NT, int RS>
+__global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict__ gmax, const uint32_t* __restrict__ aux, int64_t ldg,
+                                                          int64_t n_groups, const f16_t* __restrict__ Q, const f16_t* __restrict__ C,
+                                                          int64_t n_rows, int D, int k, float* __restrict__ out_s, int64_t* __restrict__ out_i,
+                                                          int64_t idx_base, float tau_scale, int debug_drop,
+                                                          unsigned long long* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = NT / 64;
+    constexpr int K1 = K + 1;
+    constexpr int KK = K1 > KMAX ? K1 : KMAX;
+    static_assert(3 * K >= NW && K <= 64, "fallback scratch / one lane per selected group");
+    __shared__ float w_s[NW][KK];
+    __shared__ int64_t w_i[NW][KK];
+    __shared__ int32_t sel_g[K];
+    __shared__ int64_t sel_row[K];
+    __shared__ float sel_ub2[K];
+    __shared__ float cand_s[K];
+    __shared__ int64_t cand_i[K];
+    __shared__ int32_t exp_list[K];
+    __shared__ float sh_u, sh_thr, sh_qn;
+    __shared__ int sh_flag, sh_nexp;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    f16_t* qs = reinterpret_cast<f16_t*>(smem);               // [D] query row
+    float* gs = reinterpret_cast<float*>(smem + (((size_t)D * 2 + 15) & ~(size_t)15));          // [K*64] row scores
+    int64_t* gi_ = reinterpret_cast<int64_t*>(reinterpret_cast<char*>(gs) + K * GROUP_ROWS * 4);  // [K*64] row ids
+    for (int i = tid; i < (D >> 3); i += NT)
+        reinterpret_cast<u32x4*>(qs)[i] = reinterpret_cast<const u32x4*>(Q + (int64_t)q * D)[i];
+    for (int i = tid; i < K * GROUP_ROWS; i += NT) { gs[i] = -INFINITY; gi_[i] = -1; }
+    // (1) this query's super-group maxima
+    {
+        const int64_t n_super = (n_groups + SUPER - 1) / SUPER;
+        const float* col = gmax + q;
+        float s[RS]; int64_t id[RS];
+#pragma unroll
+        for (int j = 0; j < RS; ++j) {
+            const int64_t sg = (int64_t)j * NT + tid;
+            s[j] = -INFINITY; id[j] = -1;
+            if ((int64_t)j * NT < n_super) {                    // block-uniform: skips the loads of unused rounds
+                float v[SUPER];
+#pragma unroll
+                for (int u = 0; u < SUPER; ++u) {
+                    const int64_t g = sg * SUPER + u;
+                    v[u] = col[(g < n_groups ? g : n_groups - 1) * ldg];
+                }
+                float m = v[0];
+#pragma unroll
+                for (int u = 1; u < SUPER; ++u) m = fmaxf(m, v[u]);
+                if (sg < n_super) { s[j] = m; id[j] = sg; }
+            }
+        }
+        wave_topk<RS>(s, id, K1, lane, w_s[w], w_i[w]);
+    }
+    __syncthreads();
+    if (w == 0) {
+        constexpr int R2 = (NW * K1 + 63) / 64;
+        float s[R2]; int64_t id[R2];
+#pragma unroll
+        for (int j = 0; j < R2; ++j) {
+            const int i = j * 64 + lane;
+            s[j] = i < NW * K1 ? w_s[i / K1][i % K1] : -INFINITY;
+            id[j] = i < NW * K1 ? w_i[i / K1][i % K1] : -1;
+        }
+        wave_topk<R2>(s, id, K1, lane, gs, gi_);               // K best super-groups -> gs/gi_[0..K), best left out -> [K]
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float u = gi_[K] >= 0 ? gs[K] : -INFINITY;
+        // (2) expand to K*SUPER groups, reduce to the K best groups (+ the best one left out)
+        constexpr int R3 = (K * SUPER + 63) / 64;
+        float s3[R3]; int64_t id3[R3];
+#pragma unroll
+        for (int j = 0; j < R3; ++j) {
+            const int i = j * 64 + lane;
+            s3[j] = -INFINITY; id3[j] = -1;
+            if (i < K * SUPER) {
+                const int64_t sg = gi_[i / SUPER];
+                const int64_t g = sg * SUPER + (i % SUPER);
+                if (sg >= 0 && g < n_groups) { s3[j] = gmax[g * ldg + q]; id3[j] = g; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // gs / gi_[0..K] were scratch for the super-group list: back to "empty" before the candidates go in
+        if (lane <= K) { gs[lane] = -INFINITY; gi_[lane] = -1; }
+        wave_topk<R3>(s3, id3, K1, lane, w_s[0], w_i[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (w_i[0][K] >= 0) u = fmaxf(u, w_s[0][K]);
+        if (debug_drop && w_i[0][0] >= 0) u = fmaxf(u, w_s[0][0]);
+        if (lane < K) {
+            const int32_t g = !debug_drop ? (int32_t)w_i[0][lane] : (lane + 1 < K ? (int32_t)w_i[0][lane + 1] : -1);
+            sel_g[lane] = g;
+            int64_t row = -1; float ub2 = INFINITY;
+            if (g >= 0) {
+                const uint32_t a = aux[(int64_t)g * ldg + q];
+                row = (int64_t)g * GROUP_ROWS + (int64_t)(a & 63u);
+                ub2 = __uint_as_float(a & 0xFFFF0000u);
+                // a position past the shard's end is a COPY of its last row (pass A clamps row addresses): then the copies tie with it and
+                // ub2 is its own score, so the group is expanded below; the candidate is the real row
+                row = row < n_rows ? row : n_rows - 1;
+            }
+            sel_row[lane] = row; sel_ub2[lane] = ub2;
+        }
+        float qq = 0.f;
+        for (int i = lane; i < D; i += 64) { const float v = (float)qs[i]; qq = fmaf(v, v, qq); }
+        qq = wave_sum(qq);
+        if (lane == 0) { sh_u = u; sh_qn = sqrtf(qq); }
+    }
+    __syncthreads();
+    // (3a) the K arg-max rows, exactly
+    const int nch = D >> 3, l8 = lane & 7, rsub = lane >> 3;
+    for (int t0 = w * 8; t0 < K; t0 += NW * 8) {
+        const int t = t0 + rsub;
+        const bool ok = t < K && sel_g[t < K ? t : 0] >= 0;
+        const int64_t row = ok ? sel_row[t] : 0;
+        const float a = exact_row_score(C + row * D, qs, nch, l8, ok);
+        if (l8 == 0 && t < K) { cand_s[t] = ok ? a : -INFINITY; cand_i[t] = ok ? row : -1; }
+    }
+    __syncthreads();
+    if (w == 0) {
+        const float my = lane < K ? cand_s[lane] : -INFINITY;
+        const int64_t mi = lane < K ? cand_i[lane] : -1;
+        int better = 0;
+#pragma unroll 4
+        for (int j = 0; j < K; ++j) {
+            const float sj = __shfl(my, j);
+            const int64_t ij = __shfl(mi, j);
+            better += (ij >= 0 && mi >= 0 && cand_better(sj, ij, my, mi)) ? 1 : 0;
+        }
+        const unsigned long long vmask = __ballot(mi >= 0);
+        const int nvalid = __popcll(vmask);
+        const unsigned long long kth = __ballot(mi >= 0 && better == k - 1);
+        const float sk = (nvalid >= k && kth) ? __shfl(my, __ffsll((long long)kth) - 1) : -INFINITY;
+        const float thr0 = sk > -INFINITY ? sk - tau_scale * sh_qn : -INFINITY;
+        const bool expand = lane < K && sel_g[lane < K ? lane : 0] >= 0 && (sel_ub2[lane < K ? lane : 0] >= thr0);
+        const unsigned long long em = __ballot(expand);
+        if (expand) exp_list[__popcll(em & ((1ull << lane) - 1ull))] = lane;
+        // an unexpanded group contributes its arg-max row: slot (group index, position 0)
+        if (lane < K && !expand && mi >= 0) { gs[lane * GROUP_ROWS] = my; gi_[lane * GROUP_ROWS] = mi; }
+        if (lane == 0) sh_nexp = __popcll(em);
+        if (em == 0ull) {
+            // the common case: the answer is the K candidates in rank order; nothing else to score
+            if (mi >= 0 && better < k) {
+                out_s[(int64_t)q * k + better] = my;
+                out_i[(int64_t)q * k + better] = mi + idx_base;
+            }
+            if (lane >= nvalid && lane < k) { out_s[(int64_t)q * k + lane] = -INFINITY; out_i[(int64_t)q * k + lane] = -1; }
+            const bool flag = sh_u > -INFINITY && sh_u >= thr0;
+            if (lane == 0) { sh_flag = flag ? 1 : 0; sh_thr = thr0; }
+            if (flag) {                                          // the fallback starts from the sorted list in gs / gi_[0..k)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane < K) { gs[lane * GROUP_ROWS] = -INFINITY; gi_[lane * GROUP_ROWS] = -1; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (mi >= 0 && better < k) { gs[better] = my; gi_[better] = mi; }
+            }
+        }
+    }
+    __syncthreads();
+    const int nexp = sh_nexp;
+    if (nexp > 0) {
+        // (3b) every row of the expanded groups (block-uniform branch)
+        for (int t0 = w * 8; t0 < nexp * GROUP_ROWS; t0 += NW * 8) {
+            const int t = t0 + rsub, gidx = exp_list[t >> 6], rr = t & 63;
+            const int64_t row = (int64_t)sel_g[gidx] * GROUP_ROWS + rr;
+            const bool ok = row < n_rows;
+            const float a = exact_row_score(C + row * D, qs, nch, l8, ok);
+            if (l8 == 0) { gs[gidx * GROUP_ROWS + rr] = ok ? a : -INFINITY; gi_[gidx * GROUP_ROWS + rr] = ok ? row : -1; }
+        }
+        __syncthreads();
+        constexpr int GPW = (K + NW - 1) / NW;
+        {
+            float s[GPW]; int64_t id[GPW];
+#pragma unroll
+            for (int gq = 0; gq < GPW; ++gq) {
+                const int gidx = w + gq * NW;
+                s[gq] = gidx < K ? gs[gidx * GROUP_ROWS + lane] : -INFINITY;
+                id[gq] = gidx < K ? gi_[gidx * GROUP_ROWS + lane] : -1;
+            }
+            wave_topk<GPW>(s, id, k, lane, w_s[w], w_i[w]);
+        }
+        __syncthreads();
+        if (w == 0) {
+            constexpr int R4 = (NW * KMAX + 63) / 64;
+            float s[R4]; int64_t id[R4];
+#pragma unroll
+            for (int j = 0; j < R4; ++j) {
+                const int i = j * 64 + lane;
+                s[j] = i < NW * k ? w_s[i / k][i % k] : -INFINITY;
+                id[j] = i < NW * k ? w_i[i / k][i % k] : -1;
+            }
+            wave_topk<R4>(s, id, k, lane, gs, gi_);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const bool full = gi_[k - 1] >= 0;
+            const float thr = full ? gs[k - 1] - tau_scale * sh_qn : -INFINITY;
+            const bool flag = sh_u > -INFINITY && sh_u >= thr;
+            if (lane == 0) { sh_flag = flag ? 1 : 0; sh_thr = thr; }
+            if (!flag && lane < k) {
+                out_s[(int64_t)q * k + lane] = gs[lane];
+                out_i[(int64_t)q * k + lane] = gi_[lane] >= 0 ? gi_[lane] + idx_base : -1;
+            }
+        }
+        __syncthreads();
+    }
+    if (!sh_flag) return;                                       // block-uniform
+
+    // ---- certificate fallback (as rescore_kernel's): every group whose pass-A maximum reaches the threshold and that is not among the K
+    // selected ones is rescored in full.  A selected group that was NOT expanded is skipped with them: its rows other than the arg-max
+    // row score below ub2 < thr' <= thr.  One that is needed after all (thr dropped? it cannot: s_k only grows) never arises.
+    float cs = -INFINITY; int64_t ci = -1;
+    if (w == 0 && lane < k) { cs = gs[lane]; ci = gi_[lane]; }
+    __syncthreads();
+    float* sc = gs + w * GROUP_ROWS;
+    const float thr = sh_thr;
+    unsigned long long extra = 0;
+    for (int64_t g0 = (int64_t)w * 64; g0 < n_groups; g0 += (int64_t)NW * 64) {
+        const int64_t g = g0 + lane;
+        bool sus = g < n_groups && gmax[(g < n_groups ? g : 0) * ldg + q] >= thr;
+#pragma unroll 4
+        for (int j = 0; j < K; ++j) sus = sus && (sel_g[j] != (int32_t)g);
+        unsigned long long mask = __ballot(sus);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int64_t gsel = g0 + b;
+            ++extra;
+            for (int r8 = 0; r8 < GROUP_ROWS; r8 += 8) {
+                const int rr = r8 + rsub;
+                const int64_t row = gsel * GROUP_ROWS + rr;
+                const bool ok = row < n_rows;
+                const float a = exact_row_score(C + row * D, qs, nch, l8, ok);
+                if (l8 == 0) sc[rr] = ok ? a : -INFINITY;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int64_t row = gsel * GROUP_ROWS + lane;
+            float s2[2] = {cs, sc[lane]};
+            int64_t i2[2] = {ci, row < n_rows ? row : -1};
+            wave_topk<2>(s2, i2, k, lane, w_s[w], w_i[w]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            cs = lane < k ? w_s[w][lane] : -INFINITY;
+            ci = lane < k ? w_i[w][lane] : -1;
+        }
+    }
+    if (lane < k) { w_s[w][lane] = cs; w_i[w][lane] = ci; }
+    __syncthreads();
+    if (w == 0) {
+        constexpr int R4 = (NW * KMAX + 63) / 64;
+        float s[R4]; int64_t id[R4];
+#pragma unroll
+        for (int j = 0; j < R4; ++j) {
+            const int i = j * 64 + lane;
+            s[j] = i < NW * k ? w_s[i / k][i % k] : -INFINITY;
+            id[j] = i < NW * k ? w_i[i / k][i % k] : -1;
+        }
+        wave_topk<R4>(s, id, k, lane, gs, gi_);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < k) {
+            out_s[(int64_t)q * k + lane] = gs[lane];
+            out_i[(int64_t)q * k + lane] = gi_[lane] >= 0 ? gi_[lane] + idx_base : -1;
+        }
+    }
+    if (stats && lane == 0) {
+        if (w == 0) atomicAdd(&stats[0], 1ull);
+        if (extra) atomicAdd(&stats[1], extra);
+    }
+}
+
 // ---- int8 pre-filter: the candidates beyond the K selected groups, in three coalesced / parallel steps ---------------------------------
 #define PAIR_CAP_PER_QUERY 4096      // (query, group) pairs kept per query; a query that needs more is re-run ALONE by the exhaustive kernel
 #define SURV_CAP 256                 // rows at or above the threshold kept per query
@@ -828,6 +1155,8 @@ __global__ __launch_bounds__(256) void collect_pairs_kernel(const float* __restr
             const f32x4 v = *reinterpret_cast<const f32x4*>(gmax + g * ldg + q0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                // columns [nq, ldg) of gmax are never written by pass A (stale workspace bytes): skipped by index, not by the threshold
+                if (q0 + j >= nq) continue;
                 if (!(v[j] >= t4[j])) continue;
                 const int q = q0 + j;
                 bool sel = false;
@@ -1007,10 +1336,50 @@ __global__ __launch_bounds__(256) void fill_unit_rows_kernel(f16_t* __restrict__
     for (int e = 0; e < per; ++e) out[e] = (f16_t)(v[e] * inv);
 }
 
+// Embedding-like rows (arx_fill_clustered_rows_f16_at): centre(cluster(row)) + spread * noise(row), per-dimension gain, unit-normalised.
+__device__ __forceinline__ void gauss2(uint64_t r, float& g0, float& g1) {
+    const float u1 = ((float)((r >> 40) + 1)) * (1.0f / 16777216.0f);          // (0,1]
+    const float u2 = ((float)((r >> 8) & 0xffffff)) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    g0 = rad * cs; g1 = rad * sn;
+}
+__global__ __launch_bounds__(256) void fill_clustered_rows_kernel(f16_t* __restrict__ dst, int64_t n_rows, int D, uint64_t seed, int64_t row_base,
+                                                                   int n_clusters, float spread, int n_hot, float hot_gain) {
+    const int lane = threadIdx.x & 63;
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lrow >= n_rows) return;
+    const int64_t row = lrow + row_base;
+    const uint64_t cl = splitmix64(seed ^ splitmix64(0xC105ull + (uint64_t)row)) % (uint64_t)n_clusters;
+    float v[16];
+    float sq = 0.f;
+    const int per = D / 64;
+    for (int e = 0; e < per; e += 2) {
+        const int col = lane * per + e;
+        float c0, c1, n0, n1;
+        gauss2(splitmix64(seed ^ splitmix64(0xCE17ull + cl * 1024 + (uint64_t)col)), c0, c1);
+        gauss2(splitmix64((seed + 0x5EEDull) ^ splitmix64((uint64_t)row * 1024 + (uint64_t)col)), n0, n1);
+        float g0 = 1.f, g1 = 1.f;
+        for (int h = 0; h < n_hot; ++h) {
+            const int hd = (int)(splitmix64(seed + 0x407ull * (uint64_t)(h + 1)) % (uint64_t)D);
+            g0 = hd == col ? hot_gain : g0; g1 = hd == col + 1 ? hot_gain : g1;
+        }
+        v[e] = (c0 + spread * n0) * g0; v[e + 1] = (c1 + spread * n1) * g1;
+        sq += v[e] * v[e] + v[e + 1] * v[e + 1];
+    }
+    const float inv = rsqrtf(wave_sum(sq));
+    f16_t* out = dst + lrow * D + lane * per;
+    for (int e = 0; e < per; ++e) out[e] = (f16_t)(v[e] * inv);
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct TopkWs { int64_t stats, gmax, aux, part_s, part_g, q8, qmeta, thr, selg, counters, nsurv, redo, pairs, rpairs, surv_s, surv_i, total;
                 int64_t ldg; int nsplit; int64_t n_groups; };
-static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim) {
+// has_i8: the layout arx_topk_search_i8 needs (aux word per (query, group), the quantised query batch, the candidate pipeline's lists:
+// about as much again as gmax + 64 KB per query); the fp16 pass reserves none of it.  Both layouts share their prefix
+// (stats, gmax), so arx_topk_stats reads either.
+static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim, bool has_i8) {
     TopkWs w;
     const int qb = nq < QBATCH_MAX ? nq : QBATCH_MAX;
     w.ldg = round_up64(qb, 64);
@@ -1021,34 +1390,42 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim) {
     w.nsplit = (int)(ns < 1 ? 1 : (ns > 256 ? 256 : ns));
     int64_t o = 0;
     auto take = [&](int64_t b) { int64_t r = o; o += round_up64(b, 256); return r; };
+    auto take8 = [&](int64_t b) { return take(has_i8 ? b : 0); };
     w.stats = take(16);                                          // certificate counters, at the allocation's start (zeroed per call)
     w.gmax = take(w.n_groups * w.ldg * 4);
-    w.aux = take(w.n_groups * w.ldg * 4);                        // int8 pre-filter: second bound + arg-max row per (query, group)
     w.part_s = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
     w.part_g = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
-    w.q8 = take(w.ldg * (int64_t)dim);                           // int8 pre-filter: the query batch quantised (small; always reserved)
-    w.qmeta = take(w.ldg * 8);
-    const int64_t qc = qb;                                       // int8 pre-filter: candidate pipeline state, sized by the internal query batch
-    w.thr = take(qc * 4);
-    w.selg = take(qc * KSEL_BIG * 4);
-    w.counters = take(CNT_INTS * 4);                             // see CNT_* (zeroed per batch together with nsurv, which follows)
-    w.nsurv = take(QBATCH_MAX * 4);
-    w.redo = take(qc * 4);
-    w.pairs = take(qc * PAIR_CAP_PER_QUERY * 8);
-    w.rpairs = take(qc * PAIR_CAP_PER_QUERY * 8);
-    w.surv_s = take(qc * SURV_CAP * 4);
-    w.surv_i = take(qc * SURV_CAP * 8);
+    // second bound + arg-max row per (query, group): written by the int8 pass and by the fp16 pass of small batches (<= 128 queries: the
+    // single-row tail); a wide fp16 batch (ldg up to 1 024) reserves none
+    w.aux = take((has_i8 || qb <= AUX16_MAX_NQ) ? w.n_groups * w.ldg * 4 : 0);
+    w.q8 = take8(w.ldg * (int64_t)dim);                          // the query batch quantised
+    w.qmeta = take8(w.ldg * 8);
+    const int64_t qc = qb;                                       // candidate pipeline state, sized by the internal query batch
+    w.thr = take8(qc * 4);
+    w.selg = take8(qc * KSEL_BIG * 4);
+    w.counters = take8(CNT_INTS * 4);                            // see CNT_* (zeroed per batch together with nsurv, which follows)
+    w.nsurv = take8(QBATCH_MAX * 4);
+    w.redo = take8(qc * 4);
+    w.pairs = take8(qc * PAIR_CAP_PER_QUERY * 8);
+    w.rpairs = take8(qc * PAIR_CAP_PER_QUERY * 8);
+    w.surv_s = take8(qc * SURV_CAP * 4);
+    w.surv_i = take8(qc * SURV_CAP * 8);
     w.total = o;
     return w;
 }
 
 extern "C" int64_t arx_topk_workspace_bytes(int64_t n_rows, int32_t n_queries, int32_t dim, int32_t k) {
     if (n_rows <= 0 || n_queries <= 0 || dim <= 0 || k <= 0 || k > KMAX) return -1;
-    return topk_layout(n_rows, n_queries, k, dim).total;
+    return topk_layout(n_rows, n_queries, k, dim, false).total;
+}
+extern "C" int64_t arx_topk_workspace_bytes_i8(int64_t n_rows, int32_t n_queries, int32_t dim, int32_t k) {
+    if (n_rows <= 0 || n_queries <= 0 || dim <= 0 || k <= 0 || k > KMAX || dim % 128 != 0 || dim > 1024) return -1;
+    return topk_layout(n_rows, n_queries, k, dim, true).total;
 }
 
 template <int BM, bool GLDS>
-static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D, float* gmax, int64_t ldg, hipStream_t st) {
+static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D, float* gmax, int64_t ldg, uint32_t* aux,
+                           unsigned long long* zero_stats, hipStream_t st) {
     using ML = GemmMainloop<f16_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
     auto kern = search_groupmax_kernel<BM, GLDS>;
     constexpr int smem_bytes = (BM == 256 && GLDS) ? Gemm8Phase<f16_t, 2>::STAGE_OFF : ML::SMEM_BYTES;
@@ -1056,7 +1433,7 @@ static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_row
     const int tq = cdiv(nq, BM);
     const int64_t tn = (n_rows + 255) / 256;
     ARX_REQUIRE(tq * tn < (1ll << 31), "grid too large");
-    kern<<<(int)(tq * tn), 512, smem_bytes, st>>>(Q, nq, C, n_rows, D, tq, (int)tn, gmax, ldg);
+    kern<<<(int)(tq * tn), 512, smem_bytes, st>>>(Q, nq, C, n_rows, D, tq, (int)tn, gmax, ldg, aux, zero_stats);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -1079,22 +1456,23 @@ static int launch_groupmax_i8(const int8_t* Q8, const float2* qmeta, int nq, con
 // pass A in persistent form: >= 256 queries per pass, an even number of 64-element k-tiles, rows addressable as int
 template <typename T, bool I8>
 static int launch_groupmax_persistent(const T* Q, int nq, const T* C, int64_t n_rows, int Kt, int D, const float2* qmeta, const float2* cmeta,
-                                      float* gmax, uint32_t* aux, int64_t ldg, hipStream_t st) {
+                                      float* gmax, uint32_t* aux, int64_t ldg, int cu_limit, hipStream_t st) {
     auto kern = search_groupmax_persistent_kernel<T, I8>;
     constexpr int smem_bytes = Gemm8Phase<T, 0>::SMEM_BYTES;
     ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem_bytes));
     const int tq = cdiv(nq, 256);
     const int64_t tn = (n_rows + 255) / 256;
-    const int n_cu = arx_device_cus();
+    int n_cu = arx_device_cus();
+    if (cu_limit > 0 && cu_limit < n_cu) n_cu = cu_limit;          // a CU-masked stream: one block per CU it may use
     int64_t grid = tq * tn < n_cu ? tq * tn : n_cu;
     grid = grid / 8 * 8 > 0 ? grid / 8 * 8 : 8;                   // a multiple of 8: a block keeps its XCD (and its residue class of corpus tiles)
     kern<<<(int)grid, 512, smem_bytes, st>>>(Q, nq, C, n_rows, Kt, D, tq, (int)tn, qmeta, cmeta, gmax, aux, ldg);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
-static bool persistent_pass_ok(int nq, int64_t n_rows, int k_elems) {
-    static const bool off = getenv("ARX_SEARCH_PERSISTENT") && getenv("ARX_SEARCH_PERSISTENT")[0] == '0';      // A/B switch
-    return !off && nq > 128 && n_rows < (1ll << 31) - 256 && k_elems % 128 == 0 && (int64_t)k_elems * 2 * 256 < (1ll << 31);
+static bool persistent_pass_ok(int nq, int64_t n_rows, int k_elems, int flags) {
+    return !(flags & ARX_TOPK_NO_PERSISTENT) && nq > 128 && n_rows < (1ll << 31) - 256 && k_elems % 128 == 0 &&
+           (int64_t)k_elems * 2 * 256 < (1ll << 31);
 }
 
 static int64_t i8_meta_offset(int64_t n_rows, int dim) { return round_up64(n_rows * (int64_t)dim, 256); }
@@ -1175,53 +1553,100 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
     return ARX_OK;
 }
 
-// query batches of more than this take the fp16 pass even when an int8 index is given (tuning knob).  Default = every batch size: with
-// single-row candidates (aux word) and block-aggregated candidate lists the int8 pass wins at every Qb measured (10 M x 768, same box:
-// 1.67x at Qb = 1, 1.45x at 64, 1.31x at 256, 1.40x at 1 024: profiles/r03); round 2's crossover was 128.
-#define I8_MAX_NQ_DEFAULT QBATCH_MAX
-static int g_i8_max_nq = I8_MAX_NQ_DEFAULT;
-extern "C" int32_t arx_topk_set_i8_max_queries(int32_t n) {
-    g_i8_max_nq = n < 0 ? I8_MAX_NQ_DEFAULT : n;
+// the single-kernel tail of a small fp16 batch (tail_single_kernel)
+static bool tail_single_ok(bool use_i8, int nq, int64_t n_rows) {
+    const int64_t n_groups = (n_rows + GROUP_ROWS - 1) / GROUP_ROWS, n_super = (n_groups + SUPER - 1) / SUPER;
+    return !use_i8 && nq <= AUX16_MAX_NQ && n_super <= (int64_t)TAIL_RS_MAX * 1024;
+}
+template <int K>
+static int run_tail_single(const TopkWs& L, char* ws, const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D, int k, float* out_s,
+                           int64_t* out_i, int64_t idx_base, float tau_scale, int debug_drop, hipStream_t st) {
+    const size_t smem = (((size_t)D * 2 + 15) & ~(size_t)15) + (size_t)K * GROUP_ROWS * 12;
+    const int64_t n_super = (L.n_groups + SUPER - 1) / SUPER;
+    ProfScope psc(ARX_K_SEARCH_RESCORE, st);
+    const float* gmax = (const float*)(ws + L.gmax);
+    const uint32_t* aux = (const uint32_t*)(ws + L.aux);
+    unsigned long long* stats = (unsigned long long*)(ws + L.stats);
+    if (n_super <= 2 * 1024) {
+        auto kern = tail_single_kernel<K, 1024, 2>;
+        if (smem > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)kern, (int)smem));
+        kern<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale, debug_drop, stats);
+    } else {
+        auto kern = tail_single_kernel<K, 1024, TAIL_RS_MAX>;
+        if (smem > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)kern, (int)smem));
+        kern<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale, debug_drop, stats);
+    }
+    ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
 
-// test hooks (arx_topk_set_debug): the tolerance can only be WIDENED, never read from the environment
-static float g_dbg_tau_mult = 1.0f;
-static int g_dbg_drop = 0;
-extern "C" int32_t arx_topk_set_debug(float tau_mult, int32_t drop_best) {
-    ARX_REQUIRE(tau_mult >= 1.0f, "tau_mult=%g: the certificate tolerance may only be widened (>= 1)", (double)tau_mult);
-    g_dbg_tau_mult = tau_mult;
-    g_dbg_drop = drop_best ? 1 : 0;
+// query batches of more than this take the fp16 pass even when an int8 index is given (arx_topk_options.i8_max_queries).  Default = every
+// batch size: with single-row candidates (aux word) and block-aggregated candidate lists the int8 pass wins at every Qb measured
+// (10 M x 768, same box: 1.67x at Qb = 1, 1.45x at 64, 1.31x at 256, 1.40x at 1 024: profiles/r03); round 2's crossover was 128.
+#define I8_MAX_NQ_DEFAULT QBATCH_MAX
+
+// The library keeps no search policy of its own (round 3 had three process-wide knobs here): a call's policy is its options argument.
+struct TopkPolicy { int i8_max_nq; float norm_bound; int cu_limit; int flags; float tau_mult; int drop; };
+static int resolve_policy(const arx_topk_options* opt, TopkPolicy& P) {
+    P = TopkPolicy{I8_MAX_NQ_DEFAULT, 1.0f + 1.0f / 512.0f, 0, 0, 1.0f, 0};
+    if (!opt) return ARX_OK;
+    ARX_REQUIRE(opt->struct_bytes == (int32_t)sizeof(arx_topk_options), "arx_topk_options.struct_bytes=%d, this library expects %d",
+                opt->struct_bytes, (int)sizeof(arx_topk_options));
+    if (opt->i8_max_queries != 0) P.i8_max_nq = opt->i8_max_queries < 0 ? 0 : opt->i8_max_queries;
+    if (opt->max_row_norm != 0.0f) {
+        ARX_REQUIRE(opt->max_row_norm > 0.0f && opt->max_row_norm < INFINITY, "max_row_norm=%g: must be a finite positive bound",
+                    (double)opt->max_row_norm);
+        P.norm_bound = opt->max_row_norm;
+    }
+    ARX_REQUIRE(opt->cu_limit >= 0, "cu_limit=%d", opt->cu_limit);
+    P.cu_limit = opt->cu_limit;
+    P.flags = opt->flags;
+    if (opt->debug_tau_mult != 0.0f) {
+        ARX_REQUIRE(opt->debug_tau_mult >= 1.0f, "debug_tau_mult=%g: the certificate tolerance may only be widened (>= 1)",
+                    (double)opt->debug_tau_mult);
+        P.tau_mult = opt->debug_tau_mult;
+    }
+    P.drop = opt->debug_drop_best ? 1 : 0;
     return ARX_OK;
 }
 
 static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_rows, const void* queries, int32_t n_queries, int32_t dim,
                             int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base, void* ws,
-                            int64_t ws_bytes, void* stream) {
+                            int64_t ws_bytes, const arx_topk_options* opt, void* stream) {
+    TopkPolicy P;
+    if (int prc = resolve_policy(opt, P)) return prc;
     ARX_REQUIRE(corpus && queries && out_scores && out_ids && ws, "null pointer argument");
     ARX_REQUIRE(!index_i8 || (dim % 128 == 0 && dim <= 1024), "int8 pre-filter: dim=%d must be a multiple of 128, <= 1024", dim);
     ARX_REQUIRE(!index_i8 || n_rows < (1ll << 32), "int8 pre-filter: row candidates are 32-bit");
     ARX_REQUIRE(n_rows > 0 && n_queries > 0, "empty corpus or query set");
     ARX_REQUIRE(dim > 0 && dim % 64 == 0 && dim <= 8192, "dim=%d must be a multiple of 64", dim);
     ARX_REQUIRE(k > 0 && k <= KMAX, "k=%d out of range 1..%d", k, KMAX);
-    const TopkWs L = topk_layout(n_rows, n_queries, k, dim);
-    ARX_REQUIRE(ws_bytes >= L.total, "workspace too small: %lld < %lld", (long long)ws_bytes, (long long)L.total);
+    const TopkWs L = topk_layout(n_rows, n_queries, k, dim, index_i8 != nullptr);
+    ARX_REQUIRE(ws_bytes >= L.total, "workspace too small: %lld < %lld (arx_topk_workspace_bytes%s)", (long long)ws_bytes, (long long)L.total,
+                index_i8 ? "_i8" : "");
+    ARX_REQUIRE(!(P.flags & (ARX_TOPK_SCAN_ONLY | ARX_TOPK_TAIL_ONLY)) || n_queries <= QBATCH_MAX,
+                "a split (scan / tail) search takes at most %d queries per call", QBATCH_MAX);
+    ARX_REQUIRE((P.flags & (ARX_TOPK_SCAN_ONLY | ARX_TOPK_TAIL_ONLY)) != (ARX_TOPK_SCAN_ONLY | ARX_TOPK_TAIL_ONLY), "scan-only and tail-only together");
     hipStream_t st = (hipStream_t)stream;
     const f16_t* C = (const f16_t*)corpus;
 #ifdef ARX_DEV_VARIANTS
     const char* genv = getenv("ARX_GEMM_GLDS");
     const bool glds = !(genv && genv[0] == '0');
 #endif
-    // certificate tolerance (rescore_kernel step 5): eps_A + eps_B per unit of |q|_2, corpus rows of norm <= 1 + 2^-9
-    const float tau_scale = (0.3125f * (float)dim + 4.0f) * 5.9604645e-8f * (1.0f + 1.0f / 512.0f) * g_dbg_tau_mult;   // arx_topk_set_debug: >= 1
-    const int debug_drop = g_dbg_drop;
+    // certificate tolerance (rescore_kernel step 5): eps_A + eps_B <= (0.3125 D + 4) 2^-24 |q|_2 |c|_2 (every rounding of either pass is
+    // relative to a partial sum bounded by sum |q_i c_i| <= |q|_2 |c|_2), |c|_2 <= the caller's bound on the shard's row norms
+    const float tau_scale = (0.3125f * (float)dim + 4.0f) * 5.9604645e-8f * P.norm_bound * P.tau_mult;
+    const int debug_drop = P.drop;
     for (int q0 = 0; q0 < n_queries; q0 += QBATCH_MAX) {
         const int nq = (n_queries - q0) < QBATCH_MAX ? (n_queries - q0) : QBATCH_MAX;
         const f16_t* Q = (const f16_t*)queries + (int64_t)q0 * dim;
         float* gmax = (float*)((char*)ws + L.gmax);
-        int rc;
-        const bool use_i8 = index_i8 && nq <= g_i8_max_nq;          // arx_topk_set_i8_max_queries
-        if (use_i8) {                           // pass A over the int8 representation: upper bounds instead of scores, everything after it unchanged
+        int rc = ARX_OK;
+        const bool use_i8 = index_i8 && nq <= P.i8_max_nq;          // arx_topk_options.i8_max_queries
+        const bool single = tail_single_ok(use_i8, nq, n_rows) && !(P.flags & ARX_TOPK_NO_SINGLE_ROW_TAIL);
+        if (P.flags & ARX_TOPK_TAIL_ONLY) {
+            // pass A of this batch ran in an earlier ARX_TOPK_SCAN_ONLY call on this workspace (the caller ordered the two streams)
+        } else if (use_i8) {                           // pass A over the int8 representation: upper bounds instead of scores, everything after it unchanged
             int8_t* q8 = (int8_t*)((char*)ws + L.q8);
             float2* qmeta = (float2*)((char*)ws + L.qmeta);
             quantize_rows_i8_kernel<<<cdiv(nq, 4), 256, 0, st>>>(Q, nq, dim, q8, qmeta);
@@ -1230,35 +1655,40 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
             const float2* cmeta = (const float2*)((const char*)index_i8 + i8_meta_offset(n_rows, dim));
             ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
             uint32_t* aux = (uint32_t*)((char*)ws + L.aux);
-            if (persistent_pass_ok(nq, n_rows, dim / 2))
+            if (persistent_pass_ok(nq, n_rows, dim / 2, P.flags))
                 rc = launch_groupmax_persistent<i8pair_t, true>((const i8pair_t*)q8, nq, (const i8pair_t*)C8, n_rows, dim / 2, dim, qmeta, cmeta, gmax,
-                                                                aux, L.ldg, st);
+                                                                aux, L.ldg, P.cu_limit, st);
             else
             rc = nq <= 64 ? launch_groupmax_i8<64, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
                : nq <= 128 ? launch_groupmax_i8<128, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
                            : launch_groupmax_i8<256, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st);
         } else {
         ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
+        uint32_t* aux16 = single ? (uint32_t*)((char*)ws + L.aux) : nullptr;                 // small fp16 batch: aux words for the single-kernel tail
+        unsigned long long* zs16 = (single && q0 == 0) ? (unsigned long long*)((char*)ws + L.stats) : nullptr;
 #ifdef ARX_DEV_VARIANTS
         if (!glds) {
-            rc = nq <= 64 ? launch_groupmax<64, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
-               : nq <= 128 ? launch_groupmax<128, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
-                           : launch_groupmax<256, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, st);
+            rc = nq <= 64 ? launch_groupmax<64, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)
+               : nq <= 128 ? launch_groupmax<128, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)
+                           : launch_groupmax<256, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, nullptr, nullptr, st);
         } else
 #endif
-            if (persistent_pass_ok(nq, n_rows, dim))
-                rc = launch_groupmax_persistent<f16_t, false>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, gmax, nullptr, L.ldg, st);
+            if (persistent_pass_ok(nq, n_rows, dim, P.flags))
+                rc = launch_groupmax_persistent<f16_t, false>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, gmax, nullptr, L.ldg, P.cu_limit, st);
             else
-            rc = nq <= 64 ? launch_groupmax<64, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
-               : nq <= 128 ? launch_groupmax<128, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st)
-                           : launch_groupmax<256, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, st);
+            rc = nq <= 64 ? launch_groupmax<64, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)
+               : nq <= 128 ? launch_groupmax<128, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)
+                           : launch_groupmax<256, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, nullptr, nullptr, st);
         }
         if (rc != ARX_OK) return rc;
+        if (P.flags & ARX_TOPK_SCAN_ONLY) continue;
         float* os = out_scores + (int64_t)q0 * k;
         int64_t* oi = out_ids + (int64_t)q0 * k;
         // rescore geometry (same-box A/B, r02): a 16-wave block per query is fastest while the blocks fit the chip at once
         // (0.10 vs 0.13 ms at <= 64 queries); 4-wave blocks, eight to a CU, when there are thousands (2.9 vs 5.4 ms per 10 k)
-        if (k > 10) rc = run_select_rescore<KSEL_BIG, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
+        if (single) rc = k > 10 ? run_tail_single<KSEL_BIG>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st)
+                                : run_tail_single<KSEL_SMALL>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
+        else if (k > 10) rc = run_select_rescore<KSEL_BIG, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
         else if (nq <= 128) rc = run_select_rescore<KSEL_SMALL, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
         else rc = run_select_rescore<KSEL_SMALL, 256>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
         if (rc != ARX_OK) return rc;
@@ -1269,14 +1699,53 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
 extern "C" int32_t arx_topk_search(const void* corpus, int64_t n_rows, const void* queries, int32_t n_queries, int32_t dim,
                                    int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base, void* ws,
                                    int64_t ws_bytes, void* stream) {
-    return topk_search_impl(corpus, nullptr, n_rows, queries, n_queries, dim, k, out_scores, out_ids, idx_base, ws, ws_bytes, stream);
+    return topk_search_impl(corpus, nullptr, n_rows, queries, n_queries, dim, k, out_scores, out_ids, idx_base, ws, ws_bytes, nullptr, stream);
 }
 
 extern "C" int32_t arx_topk_search_i8(const void* corpus, const void* index_i8, int64_t n_rows, const void* queries, int32_t n_queries,
                                       int32_t dim, int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base, void* ws,
                                       int64_t ws_bytes, void* stream) {
     ARX_REQUIRE(index_i8, "null int8 index");
-    return topk_search_impl(corpus, index_i8, n_rows, queries, n_queries, dim, k, out_scores, out_ids, idx_base, ws, ws_bytes, stream);
+    return topk_search_impl(corpus, index_i8, n_rows, queries, n_queries, dim, k, out_scores, out_ids, idx_base, ws, ws_bytes, nullptr, stream);
+}
+
+extern "C" int32_t arx_topk_search_opt(const void* corpus, const void* index_i8, int64_t n_rows, const void* queries, int32_t n_queries,
+                                       int32_t dim, int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base, void* ws,
+                                       int64_t ws_bytes, const arx_topk_options* opt, void* stream) {
+    return topk_search_impl(corpus, index_i8, n_rows, queries, n_queries, dim, k, out_scores, out_ids, idx_base, ws, ws_bytes, opt, stream);
+}
+
+// max row norm of a shard: one wave per row, fp32 sum of squares; non-negative floats order like their bit patterns, so the maximum is an
+// integer atomicMax (a NaN row's pattern is above +inf's and survives: the caller refuses such a shard)
+__global__ __launch_bounds__(256) void rows_max_norm_kernel(const f16_t* __restrict__ X, int64_t n_rows, int D, uint32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    float best = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_rows; row += (int64_t)gridDim.x * 4) {
+        const f16_t* x = X + row * D;
+        float a = 0.f;
+        for (int c = lane * 8; c < D; c += 512) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(x + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf((float)v[e], (float)v[e], a);
+        }
+        a = wave_sum(a);
+        best = (a > best || a != a) ? a : best;
+    }
+    if (lane == 0) {
+        const float nrm = sqrtf(best) * (1.0f + 1.0f / 4096.0f);      // rounded UP: the fp32 sum's error is below D 2^-24 relative
+        atomicMax(out, __float_as_uint(nrm));
+    }
+}
+extern "C" int32_t arx_rows_max_norm_f16(const void* rows, int64_t n_rows, int32_t dim, float* out_max, void* stream) {
+    ARX_REQUIRE(rows && out_max && n_rows > 0, "bad args");
+    ARX_REQUIRE(dim > 0 && dim % 8 == 0, "dim=%d must be a multiple of 8", dim);
+    hipStream_t st = (hipStream_t)stream;
+    ARX_HIP_CHECK(hipMemsetAsync(out_max, 0, 4, st));
+    const int64_t want = (n_rows + 3) / 4;
+    const int blocks = (int)(want < 8192 ? want : 8192);
+    rows_max_norm_kernel<<<blocks, 256, 0, st>>>((const f16_t*)rows, n_rows, dim, (uint32_t*)out_max);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
 }
 
 extern "C" int32_t arx_topk_stats(const void* ws, int64_t* flagged_queries, int64_t* extra_groups, void* stream) {
@@ -1312,3 +1781,16 @@ extern "C" int32_t arx_fill_unit_rows_f16(void* dst, int64_t n_rows, int32_t dim
     return arx_fill_unit_rows_f16_at(dst, n_rows, dim, seed, 0, stream);
 }
 
+extern "C" int32_t arx_fill_clustered_rows_f16_at(void* dst, int64_t n_rows, int32_t dim, uint64_t seed, int64_t row_base, int32_t n_clusters,
+                                                  float spread, int32_t n_hot_dims, float hot_gain, void* stream) {
+    ARX_REQUIRE(dst && n_rows > 0 && row_base >= 0, "bad args");
+    ARX_REQUIRE(dim % 128 == 0 && dim <= 1024, "dim=%d must be a multiple of 128, <= 1024", dim);
+    ARX_REQUIRE(n_clusters > 0 && n_clusters <= (1 << 20) && spread >= 0.f && n_hot_dims >= 0 && n_hot_dims <= 16 && hot_gain > 0.f,
+                "bad mixture parameters");
+    const int64_t blocks = (n_rows + 3) / 4;
+    ARX_REQUIRE(blocks < (1ll << 31), "too many rows for one launch");
+    fill_clustered_rows_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((f16_t*)dst, n_rows, dim, seed, row_base, n_clusters, spread,
+                                                                              n_hot_dims, hot_gain);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}

@@ -18,7 +18,9 @@
  *   - an opaque handle owns only its private workspace (create/destroy).
  *   - every launch goes on the caller's hipStream_t (passed as void*); no hidden synchronisation.
  *   - return 0 on success, negative on error; arx_last_error() gives the thread-local message.
- *   - one host thread per handle.
+ *   - one host thread per handle.  The search entry points keep NO process-wide state: everything a call depends on is in its
+ *     arguments (arx_topk_options) and its workspace, so different host threads may search different (or the same) shards at once,
+ *     each with its own workspace and stream.  The only process-wide state in the library is the opt-in arx_prof_* timing facility.
  */
 #ifndef ARX_H
 #define ARX_H
@@ -138,7 +140,9 @@ int32_t arx_encoder_set_tap(arx_encoder* h, int32_t layer);
 int32_t arx_build_info(void);
 
 /* ---- brute-force cosine top-k over an HBM-resident fp16 shard ------------------------------------
- *   corpus  device fp16 [n_rows, dim] row-major (unit rows => dot product = cosine), dim % 64 == 0
+ *   corpus  device fp16 [n_rows, dim] row-major, dim % 64 == 0.  Scores are DOT PRODUCTS (cosine when rows and queries are unit
+ *           vectors, as the encoder writes them); the answer is the exact top-k of those for rows of ANY norm, provided
+ *           arx_topk_options.max_row_norm bounds the rows' L2 norms (default: unit rows; arx_rows_max_norm_f16 measures it).
  *   queries device fp16 [n_queries, dim]
  *   out_scores device f32 [n_queries, k]; out_ids device int64 [n_queries, k] = local row + idx_base
  *   order: score descending, ties -> lower row index; if k > n_rows the tail is (-inf, -1)
@@ -155,12 +159,49 @@ int32_t arx_topk_search(const void* corpus, int64_t n_rows, const void* queries,
  * true fp16 score of the group's rows (quantisation error bounded analytically, csrc/search.hip).  Selection, the fp32 rescoring
  * of the fp16 rows and the exactness certificate are those of arx_topk_search, so out_scores / out_ids are the same exact top-k
  * (the certificate's exhaustive-by-threshold step absorbs the bound's slack: a few hundred 64-row groups per query on unit rows).
- * dim % 128 == 0, dim <= 1024.  `corpus` is still needed (the rescoring reads it). */
+ * dim % 128 == 0, dim <= 1024.  `corpus` is still needed (the rescoring reads it).  The int8 pass needs the LARGER workspace of
+ * arx_topk_workspace_bytes_i8 (candidate lists, a second word per (query, group)); the fp16 pass does not pay for it. */
 int64_t arx_topk_i8_index_bytes(int64_t n_rows, int32_t dim);
+int64_t arx_topk_workspace_bytes_i8(int64_t n_rows, int32_t n_queries, int32_t dim, int32_t k);
 int32_t arx_topk_build_i8(const void* corpus, int64_t n_rows, int32_t dim, void* index_i8, void* stream);
 int32_t arx_topk_search_i8(const void* corpus, const void* index_i8, int64_t n_rows, const void* queries, int32_t n_queries,
                            int32_t dim, int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base,
                            void* ws, int64_t ws_bytes, void* stream);
+
+/* Per-CALL policy of a search (nothing here is remembered by the library: two indices with different policies can be searched from two
+ * host threads at once).  Zero-initialise, set struct_bytes = sizeof(arx_topk_options), fill what differs from the defaults. */
+#define ARX_TOPK_NO_PERSISTENT 1   /* flags: take the per-tile pass-A kernel even where the persistent one applies (A/B measurements) */
+#define ARX_TOPK_NO_SINGLE_ROW_TAIL 8 /* flags: small fp16 batches take the select + rescore kernel pair (all 64 rows of each selected group) instead of
+                                      the single-kernel tail that rescoring only each group's arg-max row (A/B measurements, tests) */
+#define ARX_TOPK_SCAN_ONLY     2   /* flags: run only pass A (the scan of the shard: every CU, HBM-bound) and leave its result in the workspace */
+#define ARX_TOPK_TAIL_ONLY     4   /* flags: run only what follows pass A (select, exact rescoring, certificate) on a workspace a SCAN_ONLY call
+                                      with the same arguments filled; the caller orders the two calls (possibly on two streams with different
+                                      CU masks: the pipelined search).  Split calls take at most 1 024 queries. */
+typedef struct {
+    int32_t struct_bytes;          /* sizeof(arx_topk_options) of the caller's header */
+    int32_t i8_max_queries;        /* with an int8 index: internal query batches of more than this many queries take the fp16 first pass;
+                                      0 = library default (every batch size: the measured crossover), negative = never int8 */
+    float   max_row_norm;          /* upper bound on the L2 norm of every corpus row; 0 = unit rows (<= 1 + 2^-9, what the encoder
+                                      writes).  The exactness certificate's rounding tolerance scales with it: a bound that is too
+                                      SMALL voids the proof (answers could then differ among ~1e-5-level near-ties), too large only
+                                      sends more queries through the slow path.  arx_rows_max_norm_f16 computes it. */
+    int32_t cu_limit;              /* compute units the launch stream may use (a stream created with a CU mask); 0 = the whole device.
+                                      Sizes the persistent pass-A grid (one block per CU). */
+    int32_t flags;                 /* ARX_TOPK_* */
+    float   debug_tau_mult;        /* TEST HOOK: multiplies the certificate tolerance; 0 = 1; values in (0, 1) would SHRINK the tolerance
+                                      and void the guarantee, so they are refused (1e9 = every group rescored: an exhaustive exact scan) */
+    int32_t debug_drop_best;       /* TEST HOOK: the selection forgets its best group, as a rounding accident at the boundary would;
+                                      the certificate must recover it */
+} arx_topk_options;
+/* arx_topk_search (index_i8 == NULL) / arx_topk_search_i8 with an explicit policy; opt == NULL = defaults. */
+int32_t arx_topk_search_opt(const void* corpus, const void* index_i8, int64_t n_rows, const void* queries, int32_t n_queries,
+                            int32_t dim, int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base,
+                            void* ws, int64_t ws_bytes, const arx_topk_options* opt, void* stream);
+
+/* max over rows of the L2 norm of fp16 rows [n_rows, dim] -> *out_max (ONE device float, written by the kernels on `stream`; fp32
+ * accumulation, rounded up).  What arx_topk_options.max_row_norm wants for a shard that was not written by the encoder (rows loaded
+ * from a user's .npy).  A non-finite row gives +inf/NaN: refuse to index such a shard. */
+int32_t arx_rows_max_norm_f16(const void* rows, int64_t n_rows, int32_t dim, float* out_max, void* stream);
 
 /* Exactness certificate of the LAST arx_topk_search on this workspace (csrc/search.hip, rescore_kernel step 5): the number of
  * queries whose first selection could not be certified (an unscored 64-row group reached the k-th exact score minus the
@@ -168,15 +209,17 @@ int32_t arx_topk_search_i8(const void* corpus, const void* index_i8, int64_t n_r
  * counters say how often the slow path ran (near-duplicate chunks).  Copies 16 bytes to the host and waits on `stream`. */
 int32_t arx_topk_stats(const void* ws, int64_t* flagged_queries, int64_t* extra_groups, void* stream);
 
-/* Tuning knob of arx_topk_search_i8: query batches of more than `n` queries take the fp16 first pass even though an int8 index was
- * given (0 = never use the int8 pass, a negative n restores the built-in default).  Answers are the same exact top-k either way; the default is the measured crossover. */
-int32_t arx_topk_set_i8_max_queries(int32_t n);
-
-/* TEST HOOKS of the certificate (no effect on a product run: both default to off and nothing in the package calls this).
- * tau_mult >= 1 multiplies the certificate tolerance (1e9 = the fallback rescoring every group: an exhaustive exact scan); values below 1
- * would SHRINK the tolerance and void the exactness guarantee, so they are refused.  drop_best != 0 makes the selection forget its best
- * group, as a rounding accident at the boundary would: the certificate must recover it.  Process-wide; (1.0, 0) restores the defaults. */
-int32_t arx_topk_set_debug(float tau_mult, int32_t drop_best);
+/* A HIP stream restricted to a subset of the compute units (hipExtStreamCreateWithCUMask): bit i of cu_mask = CU i in the driver's
+ * enumeration, which deals consecutive bits round-robin to the 8 XCDs — a contiguous run of 8 n bits is n CUs on every XCD.  The
+ * pipelined search (ShardIndex.search_many) runs pass A of batch b + 1 on most CUs and the select / rescore / merge tail of batch b on a
+ * few, so that the tail's whole-CU blocks never wait for pass-A blocks to drain.  *out is a hipStream_t. */
+int32_t arx_stream_create_cu_mask(const uint32_t* cu_mask, int32_t n_words, void** out);
+int32_t arx_stream_destroy(void* stream);
+/* compute units of the current device */
+int32_t arx_device_cu_count(void);
+/* Debug: out[b] (device uint32 [n_blocks]) = (XCC_ID << 16) | (HW_ID & 0xffff) of the CU that ran block b of a grid of one-wave blocks that
+ * each idle for spin_cycles — which compute units the stream's queue really uses (HW_ID: bits 8-11 CU, 12 shader array, 13-15 engine). */
+int32_t arx_debug_cu_census(uint32_t* out, int32_t n_blocks, int32_t spin_cycles, void* stream);
 
 /* Merge P partial top-k lists (e.g. the all-gathered per-shard results) into the global top-k.
  *   scores f32 [P, n_queries, k], ids int64 [P, n_queries, k] (device) -> out [n_queries, k]. */
@@ -229,6 +272,13 @@ int32_t arx_fill_unit_rows_f16(void* dst, int64_t n_rows, int32_t dim, uint64_t 
  * write for this seed — every rank of a sharded bench fills its own slice of ONE corpus (bench cfg 4: 5 M rows cut 8 ways), so that
  * the merged answer can be checked against a single-index search of the same rows. */
 int32_t arx_fill_unit_rows_f16_at(void* dst, int64_t n_rows, int32_t dim, uint64_t seed, int64_t row_base, void* stream);
+/* EMBEDDING-LIKE synthetic rows (bench: search on something harder than iid Gaussian directions): row r belongs to cluster
+ * hash(seed, r) % n_clusters and is centre(cluster) + spread * noise(r), both N(0,1) per dimension times a per-dimension gain that is
+ * hot_gain on n_hot_dims dimensions chosen by the seed (outlier dimensions: they set max|x| and with it the int8 scale of every row)
+ * and 1 elsewhere; L2-normalised, fp16.  Rows of the same seed share the centres whatever row_base is, so queries drawn with a
+ * row_base beyond the corpus are new points of the same mixture.  dim % 128 == 0, dim <= 1024. */
+int32_t arx_fill_clustered_rows_f16_at(void* dst, int64_t n_rows, int32_t dim, uint64_t seed, int64_t row_base, int32_t n_clusters,
+                                       float spread, int32_t n_hot_dims, float hot_gain, void* stream);
 
 /* ---- live per-kernel timing (bench.py roofline leg) ----------------------------------------------
  * When enabled, every launch of a hot kernel class is bracketed by hipEvents recorded on the launch

@@ -13,12 +13,12 @@ Q = fill_unit_rows(2048, D, seed=11)
 out = {}
 for tag, pre in (("fp16", None), ("int8", "int8")):
     idx = ShardIndex(corpus, prefilter=pre)
-    _lib.load().arx_topk_set_i8_max_queries(1 << 30)
     for qb in (1, 16, 64, 128, 256, 1024):
-        for _ in range(2): idx.search(Q[:qb], 10)
+        fl = _lib.TOPK_NO_PERSISTENT if os.environ.get("PROBE_NO_PERSISTENT") == "1" else 0     # A/B arm: the per-tile pass-A kernel
+        for _ in range(2): idx.search(Q[:qb], 10, flags=fl)
         _lib.prof_reset(); _lib.prof_classes(None); _lib.prof_enable(True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        for r in range(10): idx.search(Q[r * 7:r * 7 + qb], 10)
+        for r in range(10): idx.search(Q[r * 7:r * 7 + qb], 10, flags=fl)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
         _lib.prof_enable(False)
         p = _lib.prof_read()
