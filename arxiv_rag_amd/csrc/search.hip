@@ -23,8 +23,8 @@
 #define SUPER 16                      // groups per super-group in the selection pass
 #define SEL_SPLIT_WAVES 4            // waves per select block
 #define QBATCH_MAX 1024              // queries per internal pass (bounds the gmax workspace)
-#define AUX16_MAX_NQ 128              // fp16 pass: query batches up to this size write aux words and take the single-kernel tail
-#define TAIL_RS_MAX 16                // ... when the shard has at most TAIL_RS_MAX x 1024 super-groups (16.7 M rows)
+#define AUX16_MAX_NQ 256              // fp16 pass: query batches up to this size (one 256-query tile) write aux words and take the single-row tail
+#define TAIL_INBLOCK_MAX_SUPER 1024   // ... on shards of up to this many super-groups (1 M rows): there the block also selects for itself
 #define CNT_QCOUNT 2                 // layout of the int8 candidate pipeline's counter block: see collect_pairs_kernel
 #define CNT_QOVER (2 + QBATCH_MAX)
 #define CNT_INTS (2 + 2 * QBATCH_MAX)
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
 // work (profiles/r03).  Here one block per CU walks its tiles with the operand stream running through the tile boundaries.
 // Tile order: block b belongs to XCD b % 8 and takes corpus tiles = b % 8 (mod 8); inside an XCD the sequence is query-tile fastest, so
 // the (up to four) blocks that read one corpus tile are neighbours in time on ONE L2.
-template <bool I8>
+template <bool I8, bool AUX16 = false>
 struct SearchTilePolicy {
     static constexpr bool REBASE_W = true;
     static constexpr bool PERMUTE_B = false;                     // a group's arg-max row is a position inside the tile: corpus rows stay in order
@@ -423,7 +423,9 @@ struct SearchTilePolicy {
             groupmax_epilogue_i8<8, 4>(acc, MetaFromLds{meta, wc, (lane >> 4) * 4},
                                        [&](int i) { return *reinterpret_cast<const float2*>(qmeta_l + i * 32); },
                                        D, gmax + g * ldg, aux + g * ldg, m0 + wr * 128, nq, lane);
-        } else
+        } else if constexpr (AUX16)
+            groupmax_epilogue_f16_aux<8, 4>(acc, gmax + g * ldg, aux + g * ldg, m0 + wr * 128, nq, lane);
+        else
             groupmax_epilogue_f16<8, 4>(acc, gmax + g * ldg, m0 + wr * 128, nq, lane);
     }
 #ifdef ARX_STAMP
@@ -431,13 +433,15 @@ struct SearchTilePolicy {
 #endif
 };
 
-template <typename T, bool I8>
+template <typename T, bool I8, bool AUX16>
 __global__ __launch_bounds__(512) void search_groupmax_persistent_kernel(const T* __restrict__ Q, int nq, const T* __restrict__ C, int64_t n_rows,
                                                                           int Kt /* row length in T elements */, int D, int tiles_q, int tiles_n,
                                                                           const float2* __restrict__ qmeta, const float2* __restrict__ cmeta,
-                                                                          float* __restrict__ gmax, uint32_t* __restrict__ aux, int64_t ldg) {
+                                                                          float* __restrict__ gmax, uint32_t* __restrict__ aux, int64_t ldg,
+                                                                          unsigned long long* __restrict__ zero_stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const SearchTilePolicy<I8> pol{tiles_q, tiles_n, nq, D, n_rows, ldg, gmax, aux, qmeta, cmeta};
+    if (zero_stats && blockIdx.x == 0 && threadIdx.x < 2) zero_stats[threadIdx.x] = 0ull;
+    const SearchTilePolicy<I8, AUX16> pol{tiles_q, tiles_n, nq, D, n_rows, ldg, gmax, aux, qmeta, cmeta};
     gemm8_persistent_body<T>(Q, Kt, C, Kt, nq, (int)n_rows, Kt, pol, smem);
 }
 
@@ -856,12 +860,25 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
 //   (4) top-k of the candidates; (5) certificate exactly as rescore_kernel's: U bounds every row in a group that was not selected; rows of a
 //       selected, unexpanded group other than its arg-max row have pass-A score <= ub2 < thr' <= thr (s_k only grows as rows are added),
 //       so they are covered too.  The fallback (every unscored group with gmax >= thr) is the same code.
-template <int K, int NT, int RS>
+template <int K, int NT, int RS, bool INBLOCK, bool COLLECT>
 __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict__ gmax, const uint32_t* __restrict__ aux, int64_t ldg,
-                                                          int64_t n_groups, const f16_t* __restrict__ Q, const f16_t* __restrict__ C,
+                                                          int64_t n_groups, const float* __restrict__ part_s, const int32_t* __restrict__ part_g,
+                                                          int nslices, const f16_t* __restrict__ Q, const f16_t* __restrict__ C,
                                                           int64_t n_rows, int D, int k, float* __restrict__ out_s, int64_t* __restrict__ out_i,
                                                           int64_t idx_base, float tau_scale, int debug_drop,
-                                                          unsigned long long* __restrict__ stats) {
+                                                          unsigned long long* __restrict__ stats,
+                                                          float* __restrict__ thr_out, int32_t* __restrict__ selg_out,
+                                                          int* __restrict__ cand_counters, int* __restrict__ cand_nsurv,
+                                                          const int32_t* __restrict__ only_if, unsigned long long* __restrict__ zero_stats) {
+    // only_if: run only for the queries it flags (the int8 pipeline's last step: a query whose own candidate lists overflowed is answered
+    // by this kernel's certificate fallback, i.e. exhaustively above the threshold).  zero_stats (COLLECT, first internal pass): the call's
+    // certificate counters start at zero here — no other block of a COLLECT launch touches them, the kernels that add to them run later.
+    if (only_if && !only_if[blockIdx.x]) return;
+    if (zero_stats && blockIdx.x == 0 && threadIdx.x < 2) zero_stats[threadIdx.x] = 0ull;
+    // COLLECT (int8 pre-filter; gmax / aux are UPPER BOUNDS there): write the provisional top-k, the threshold s_k - tau and the K selected
+    // groups, start this query's candidate counters at zero, and leave everything at or above the threshold to collect_pairs /
+    // pair_rescore / merge_survivors.  A selected group that was not expanded is skipped there like an expanded one: its rows other than
+    // the arg-max row have TRUE scores <= ub2 < thr.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = NT / 64;
     constexpr int K1 = K + 1;
@@ -884,8 +901,30 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
     for (int i = tid; i < (D >> 3); i += NT)
         reinterpret_cast<u32x4*>(qs)[i] = reinterpret_cast<const u32x4*>(Q + (int64_t)q * D)[i];
     for (int i = tid; i < K * GROUP_ROWS; i += NT) { gs[i] = -INFINITY; gi_[i] = -1; }
-    // (1) this query's super-group maxima
-    {
+    // (1) this query's super-group maxima: read here (INBLOCK: shards of up to ~2 M rows — one CU walking the column of a 10 M-row shard,
+    // 156 k strided loads, takes longer than the select grid it replaces: 0.21 against 0.13 ms per 64-query batch) or taken from the select
+    // kernel's partial lists (RS = candidates per lane of up to 256 slices x K entries)
+    __shared__ float w_vb[NW];
+    if constexpr (!INBLOCK) {
+        const int ncand = nslices * K;
+        float s[RS]; int64_t id[RS];
+        float vb = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < RS; ++j) {
+            const int i = (w * RS + j) * 64 + lane;
+            s[j] = -INFINITY; id[j] = -1;
+            if (i < ncand) {
+                const int sl = i / K, pp = i - sl * K;
+                const int64_t o = ((int64_t)sl * ldg + q) * K + pp;
+                s[j] = part_s[o]; id[j] = part_g[o];
+                if (pp == K - 1 && id[j] >= 0) vb = fmaxf(vb, s[j]);       // whatever this slice dropped scores <= its K-th kept value
+            }
+        }
+        wave_topk<RS>(s, id, K1, lane, w_s[w], w_i[w]);
+        vb = wave_max(vb);
+        if (lane == 0) w_vb[w] = vb;
+    } else {
+        if (lane == 0) w_vb[w] = -INFINITY;
         const int64_t n_super = (n_groups + SUPER - 1) / SUPER;
         const float* col = gmax + q;
         float s[RS]; int64_t id[RS];
@@ -894,15 +933,18 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
             const int64_t sg = (int64_t)j * NT + tid;
             s[j] = -INFINITY; id[j] = -1;
             if ((int64_t)j * NT < n_super) {                    // block-uniform: skips the loads of unused rounds
-                float v[SUPER];
+                float m = -INFINITY;
+#pragma unroll 1
+                for (int h = 0; h < SUPER; h += 8) {            // eight loads in flight at a time (sixteen cost the K = 36 instance three spilled registers)
+                    float v[8];
 #pragma unroll
-                for (int u = 0; u < SUPER; ++u) {
-                    const int64_t g = sg * SUPER + u;
-                    v[u] = col[(g < n_groups ? g : n_groups - 1) * ldg];
+                    for (int u = 0; u < 8; ++u) {
+                        const int64_t g = sg * SUPER + h + u;
+                        v[u] = col[(g < n_groups ? g : n_groups - 1) * ldg];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
                 }
-                float m = v[0];
-#pragma unroll
-                for (int u = 1; u < SUPER; ++u) m = fmaxf(m, v[u]);
                 if (sg < n_super) { s[j] = m; id[j] = sg; }
             }
         }
@@ -921,6 +963,8 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
         wave_topk<R2>(s, id, K1, lane, gs, gi_);               // K best super-groups -> gs/gi_[0..K), best left out -> [K]
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float u = gi_[K] >= 0 ? gs[K] : -INFINITY;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) u = fmaxf(u, w_vb[ww]);
         // (2) expand to K*SUPER groups, reduce to the K best groups (+ the best one left out)
         constexpr int R3 = (K * SUPER + 63) / 64;
         float s3[R3]; int64_t id3[R3];
@@ -999,8 +1043,16 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
                 out_i[(int64_t)q * k + better] = mi + idx_base;
             }
             if (lane >= nvalid && lane < k) { out_s[(int64_t)q * k + lane] = -INFINITY; out_i[(int64_t)q * k + lane] = -1; }
-            const bool flag = sh_u > -INFINITY && sh_u >= thr0;
+            const bool flag = !COLLECT && sh_u > -INFINITY && sh_u >= thr0;
             if (lane == 0) { sh_flag = flag ? 1 : 0; sh_thr = thr0; }
+            if constexpr (COLLECT) {
+                if (lane == 0) {
+                    thr_out[q] = thr0;
+                    cand_counters[CNT_QCOUNT + q] = 0; cand_counters[CNT_QOVER + q] = 0; cand_nsurv[q] = 0;
+                    if (q == 0) { cand_counters[0] = 0; cand_counters[1] = 0; }
+                }
+                if (lane < K) selg_out[q * K + lane] = sel_g[lane];
+            }
             if (flag) {                                          // the fallback starts from the sorted list in gs / gi_[0..k)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane < K) { gs[lane * GROUP_ROWS] = -INFINITY; gi_[lane * GROUP_ROWS] = -1; }
@@ -1046,16 +1098,24 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const bool full = gi_[k - 1] >= 0;
             const float thr = full ? gs[k - 1] - tau_scale * sh_qn : -INFINITY;
-            const bool flag = sh_u > -INFINITY && sh_u >= thr;
+            const bool flag = !COLLECT && sh_u > -INFINITY && sh_u >= thr;
             if (lane == 0) { sh_flag = flag ? 1 : 0; sh_thr = thr; }
             if (!flag && lane < k) {
                 out_s[(int64_t)q * k + lane] = gs[lane];
                 out_i[(int64_t)q * k + lane] = gi_[lane] >= 0 ? gi_[lane] + idx_base : -1;
             }
+            if constexpr (COLLECT) {
+                if (lane == 0) {
+                    thr_out[q] = thr;
+                    cand_counters[CNT_QCOUNT + q] = 0; cand_counters[CNT_QOVER + q] = 0; cand_nsurv[q] = 0;
+                    if (q == 0) { cand_counters[0] = 0; cand_counters[1] = 0; }
+                }
+                if (lane < K) selg_out[q * K + lane] = sel_g[lane];
+            }
         }
         __syncthreads();
     }
-    if (!sh_flag) return;                                       // block-uniform
+    if (COLLECT || !sh_flag) return;                            // block-uniform
 
     // ---- certificate fallback (as rescore_kernel's): every group whose pass-A maximum reaches the threshold and that is not among the K
     // selected ones is rescored in full.  A selected group that was NOT expanded is skipped with them: its rows other than the arg-max
@@ -1144,14 +1204,18 @@ __global__ __launch_bounds__(256) void collect_pairs_kernel(const float* __restr
     __shared__ int ln[2], lbase[2];
     if (threadIdx.x < 2) ln[threadIdx.x] = 0;
     __syncthreads();
-    const int q0 = threadIdx.x * 4;
-    if (q0 < ldg) {
+    // ldg / 4 threads cover one group's row of queries (4 each); the block's 256 threads take 1 024 / ldg groups per step (round 3 gave a
+    // block ONE group per step: with 256 queries per pass three quarters of its threads idled, and a 625 k-row shard had 153 such blocks —
+    // 153 waves doing the whole candidate step of a 256-query batch, 0.25 ms of a 0.63-ms batch)
+    const int qpr = (int)(ldg >> 2), gpi = 256 / qpr;
+    const int q0 = (threadIdx.x % qpr) * 4, tg = threadIdx.x / qpr;
+    {
         float t4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) t4[j] = (q0 + j < nq) ? thr[q0 + j] : INFINITY;
         const int64_t g0 = (int64_t)blockIdx.x * gpb;
         const int64_t g1 = g0 + gpb < n_groups ? g0 + gpb : n_groups;
-        for (int64_t g = g0; g < g1; ++g) {
+        for (int64_t g = g0 + tg; g < g1; g += gpi) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(gmax + g * ldg + q0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1397,7 +1461,7 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim, bool has_i8) {
     w.part_g = take((int64_t)w.nsplit * w.ldg * KSEL_BIG * 4);
     // second bound + arg-max row per (query, group): written by the int8 pass and by the fp16 pass of small batches (<= 128 queries: the
     // single-row tail); a wide fp16 batch (ldg up to 1 024) reserves none
-    w.aux = take((has_i8 || qb <= AUX16_MAX_NQ) ? w.n_groups * w.ldg * 4 : 0);
+    w.aux = take((has_i8 || (qb <= AUX16_MAX_NQ && n_super <= TAIL_INBLOCK_MAX_SUPER)) ? w.n_groups * w.ldg * 4 : 0);
     w.q8 = take8(w.ldg * (int64_t)dim);                          // the query batch quantised
     w.qmeta = take8(w.ldg * 8);
     const int64_t qc = qb;                                       // candidate pipeline state, sized by the internal query batch
@@ -1454,10 +1518,11 @@ static int launch_groupmax_i8(const int8_t* Q8, const float2* qmeta, int nq, con
 }
 
 // pass A in persistent form: >= 256 queries per pass, an even number of 64-element k-tiles, rows addressable as int
-template <typename T, bool I8>
+template <typename T, bool I8, bool AUX16 = false>
 static int launch_groupmax_persistent(const T* Q, int nq, const T* C, int64_t n_rows, int Kt, int D, const float2* qmeta, const float2* cmeta,
-                                      float* gmax, uint32_t* aux, int64_t ldg, int cu_limit, hipStream_t st) {
-    auto kern = search_groupmax_persistent_kernel<T, I8>;
+                                      float* gmax, uint32_t* aux, int64_t ldg, int cu_limit, hipStream_t st,
+                                      unsigned long long* zero_stats = nullptr) {
+    auto kern = search_groupmax_persistent_kernel<T, I8, AUX16>;
     constexpr int smem_bytes = Gemm8Phase<T, 0>::SMEM_BYTES;
     ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem_bytes));
     const int tq = cdiv(nq, 256);
@@ -1466,7 +1531,7 @@ static int launch_groupmax_persistent(const T* Q, int nq, const T* C, int64_t n_
     if (cu_limit > 0 && cu_limit < n_cu) n_cu = cu_limit;          // a CU-masked stream: one block per CU it may use
     int64_t grid = tq * tn < n_cu ? tq * tn : n_cu;
     grid = grid / 8 * 8 > 0 ? grid / 8 * 8 : 8;                   // a multiple of 8: a block keeps its XCD (and its residue class of corpus tiles)
-    kern<<<(int)grid, 512, smem_bytes, st>>>(Q, nq, C, n_rows, Kt, D, tq, (int)tn, qmeta, cmeta, gmax, aux, ldg);
+    kern<<<(int)grid, 512, smem_bytes, st>>>(Q, nq, C, n_rows, Kt, D, tq, (int)tn, qmeta, cmeta, gmax, aux, ldg, zero_stats);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -1489,6 +1554,94 @@ extern "C" int32_t arx_topk_build_i8(const void* corpus, int64_t n_rows, int32_t
     ARX_REQUIRE(blocks < (1ll << 31), "too many rows for one launch");
     quantize_rows_i8_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)corpus, n_rows, dim, (int8_t*)index_i8,
                                                                          (float2*)((char*)index_i8 + i8_meta_offset(n_rows, dim)));
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
+static int launch_collect_rescore(const TopkWs& L, char* ws, const float* gmax, const uint32_t* aux, int64_t n_rows, int nq, const float* thr,
+                                  const int32_t* selg, int K, const f16_t* Q, const f16_t* C, int D, float* surv_s, int64_t* surv_i, int* nsurv,
+                                  int* counters, hipStream_t st) {
+    // Candidate step, two launches: collect_pairs (lists) -> pair_rescore (a balanced grid over ALL candidates).  A fused form — the block
+    // that finds a candidate rescoring it, no lists — was built and measured in round 4 (profiles/r04/i8_candidate_step_fused_ab.md): it
+    // wins 10 % at <= 128 queries and loses 25-50 % at 256 and 1 024 (a block is then ~25 us of dependent round trips at four blocks per
+    // CU); the pair stays.
+    unsigned long long* pairs = (unsigned long long*)(ws + L.pairs);
+    unsigned long long* rpairs = (unsigned long long*)(ws + L.rpairs);
+    // groups per block: a multiple of the 1 024 / ldg groups a block takes per step; ~2 048 blocks, at most 64 groups each
+    const int gpi = (int)(1024 / L.ldg);
+    int64_t gpb = (L.n_groups + 2047) / 2048;
+    gpb = (gpb + gpi - 1) / gpi * gpi;
+    if (gpb < gpi) gpb = gpi;
+    if (gpb > 64) gpb = 64 > gpi ? 64 : gpi;
+    const int64_t blocks = (L.n_groups + gpb - 1) / gpb;
+    ARX_REQUIRE(blocks < (1ll << 31), "grid too large");
+    collect_pairs_kernel<<<(int)blocks, 256, 0, st>>>(gmax, aux, L.ldg, L.n_groups, n_rows, nq, thr, selg, K, pairs, rpairs, counters, (int)gpb);
+    ARX_HIP_CHECK(hipGetLastError());
+    pair_rescore_kernel<<<2048, 256, 0, st>>>(pairs, rpairs, counters, Q, C, n_rows, D, thr, surv_s, surv_i, nsurv);
+    ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
+// The int8 pipeline with ONE row per selected group in its first step (default; aux is written by the int8 pass anyway):
+//   [select_groups, only on shards beyond TAIL_INBLOCK_MAX_SUPER super-groups] -> tail_single_kernel<COLLECT> (provisional top-k, threshold,
+//   selected groups) -> collect_pairs -> pair_rescore (every other (query, group) at or above the threshold: one row of it where the aux
+//   word allows) -> merge_survivors -> tail_single_kernel<only_if> (a query whose own lists overflowed: exhaustive above the threshold).
+// Five launches on a small shard (round 3: six, and 0.47 ms of a 0.63-ms 256-query batch on 625 k rows).
+template <int K>
+static int run_i8_single(const TopkWs& L, char* ws, const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D, int k, float* out_s,
+                         int64_t* out_i, int64_t idx_base, float tau_scale, int debug_drop, hipStream_t st, bool first_pass) {
+    float* gmax = (float*)(ws + L.gmax);
+    const uint32_t* aux = (const uint32_t*)(ws + L.aux);
+    float* ps = (float*)(ws + L.part_s);
+    int32_t* pg = (int32_t*)(ws + L.part_g);
+    float* thr = (float*)(ws + L.thr);
+    int32_t* selg = (int32_t*)(ws + L.selg);
+    int* counters = (int*)(ws + L.counters);
+    int* nsurv = (int*)(ws + L.nsurv);
+    int32_t* redo = (int32_t*)(ws + L.redo);
+    float* surv_s = (float*)(ws + L.surv_s);
+    int64_t* surv_i = (int64_t*)(ws + L.surv_i);
+    unsigned long long* stats = (unsigned long long*)(ws + L.stats);
+    const int64_t n_super = (L.n_groups + SUPER - 1) / SUPER;
+    // (k > 10: the K = 36 in-block COLLECT instance needs 3 registers more than a 1 024-thread block may have; it takes the select kernel)
+    const bool inblock = n_super <= TAIL_INBLOCK_MAX_SUPER && K == KSEL_SMALL;
+    const size_t smem = (((size_t)D * 2 + 15) & ~(size_t)15) + (size_t)K * GROUP_ROWS * 12;
+    constexpr int R1 = (256 * K + 1023) / 1024;
+    if (!inblock) {
+        dim3 grid(cdiv(nq, 64), L.nsplit);
+        const int smem_sel = SEL_SPLIT_WAVES * K * 64 * 8;
+        auto ksel = select_groups_kernel<K>;
+        if (smem_sel > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)ksel, smem_sel));
+        ProfScope psc(ARX_K_SEARCH_SELECT, st);
+        ksel<<<grid, 256, smem_sel, st>>>(gmax, L.ldg, n_super, L.n_groups, nq, L.nsplit, ps, pg, first_pass ? stats : nullptr);
+        ARX_HIP_CHECK(hipGetLastError());
+    }
+    ProfScope psc(ARX_K_SEARCH_RESCORE, st);
+    auto k_in_c = tail_single_kernel<KSEL_SMALL, 1024, 1, true, true>;
+    auto k_in_r = tail_single_kernel<KSEL_SMALL, 1024, 1, true, false>;
+    auto k_pl_c = tail_single_kernel<K, 1024, R1, false, true>;
+    auto k_pl_r = tail_single_kernel<K, 1024, R1, false, false>;
+    if (smem > 48 * 1024) {
+        ARX_HIP_CHECK(arx_func_smem((const void*)(inblock ? k_in_c : k_pl_c), (int)smem));
+        ARX_HIP_CHECK(arx_func_smem((const void*)(inblock ? k_in_r : k_pl_r), (int)smem));
+    }
+    if (inblock)
+        k_in_c<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, nullptr, nullptr, 0, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
+                                       debug_drop, nullptr, thr, selg, counters, nsurv, nullptr, first_pass ? stats : nullptr);
+    else
+        k_pl_c<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, ps, pg, L.nsplit, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
+                                       debug_drop, nullptr, thr, selg, counters, nsurv, nullptr, nullptr);
+    ARX_HIP_CHECK(hipGetLastError());
+    if (int rc = launch_collect_rescore(L, ws, gmax, aux, n_rows, nq, thr, selg, K, Q, C, D, surv_s, surv_i, nsurv, counters, st)) return rc;
+    merge_survivors_kernel<<<cdiv(nq, 4), 256, 0, st>>>(out_s, out_i, nq, k, idx_base, surv_s, surv_i, nsurv, counters, redo, stats);
+    ARX_HIP_CHECK(hipGetLastError());
+    // (merge_survivors already counted the queries that go through this)
+    if (inblock)
+        k_in_r<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, nullptr, nullptr, 0, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
+                                       debug_drop, nullptr, nullptr, nullptr, nullptr, nullptr, redo, nullptr);
+    else
+        k_pl_r<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, ps, pg, L.nsplit, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
+                                       debug_drop, nullptr, nullptr, nullptr, nullptr, nullptr, redo, nullptr);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -1522,29 +1675,20 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
         ARX_HIP_CHECK(hipGetLastError());
         return ARX_OK;
     }
-    // int8 pre-filter: provisional top-k + threshold, then the candidate pipeline, then (only for queries whose
+    // int8 pre-filter: provisional top-k + threshold, then the candidate step, then (only for queries whose own
     // lists overflowed) the exhaustive kernel
     float* thr = (float*)(ws + L.thr);
     int32_t* selg = (int32_t*)(ws + L.selg);
     int* counters = (int*)(ws + L.counters);
     int* nsurv = (int*)(ws + L.nsurv);
     int32_t* redo = (int32_t*)(ws + L.redo);
-    unsigned long long* pairs = (unsigned long long*)(ws + L.pairs);
-    unsigned long long* rpairs = (unsigned long long*)(ws + L.rpairs);
     const uint32_t* aux = (const uint32_t*)(ws + L.aux);
     float* surv_s = (float*)(ws + L.surv_s);
     int64_t* surv_i = (int64_t*)(ws + L.surv_i);
     kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
                                debug_drop, nullptr, thr, selg, nullptr, counters, nsurv);
     ARX_HIP_CHECK(hipGetLastError());
-    {
-        const int gpb = 64;                                          // groups per block: 64 x ldg x 4 B = 16-256 KB of gmax per block
-        collect_pairs_kernel<<<(int)((L.n_groups + gpb - 1) / gpb), 256, 0, st>>>(gmax, aux, L.ldg, L.n_groups, n_rows, nq, thr, selg, K, pairs, rpairs,
-                                                                                  counters, gpb);
-    }
-    ARX_HIP_CHECK(hipGetLastError());
-    pair_rescore_kernel<<<2048, 256, 0, st>>>(pairs, rpairs, counters, Q, C, n_rows, D, thr, surv_s, surv_i, nsurv);
-    ARX_HIP_CHECK(hipGetLastError());
+    if (int rc = launch_collect_rescore(L, ws, gmax, aux, n_rows, nq, thr, selg, K, Q, C, D, surv_s, surv_i, nsurv, counters, st)) return rc;
     merge_survivors_kernel<<<cdiv(nq, 4), 256, 0, st>>>(out_s, out_i, nq, k, idx_base, surv_s, surv_i, nsurv, counters, redo, stats);
     ARX_HIP_CHECK(hipGetLastError());
     kern<<<nq, NT, smem, st>>>(ps, pg, nslices, L.ldg, gmax, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
@@ -1554,28 +1698,24 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
 }
 
 // the single-kernel tail of a small fp16 batch (tail_single_kernel)
+// fp16 pass: the aux epilogue costs pass A 3-4 % at <= 64 queries, 7 % at 128, 10-17 % at 256 (VALU work the HBM- / MFMA-bound loop does not
+// hide); the tail saves 0.03 ms (<= 64 queries) to 0.08 ms (256) per batch.  Same box, same binary, arms interleaved
+// (profiles/r04/tail_single_row_ab.md): a win at 625 k rows for every batch size (0.228 against 0.258 ms at 64 queries), break-even at
+// 2 M rows, a loss beyond.  Hence: shards of up to TAIL_INBLOCK_MAX_SUPER super-groups (1 M rows).
 static bool tail_single_ok(bool use_i8, int nq, int64_t n_rows) {
     const int64_t n_groups = (n_rows + GROUP_ROWS - 1) / GROUP_ROWS, n_super = (n_groups + SUPER - 1) / SUPER;
-    return !use_i8 && nq <= AUX16_MAX_NQ && n_super <= (int64_t)TAIL_RS_MAX * 1024;
+    return !use_i8 && nq <= AUX16_MAX_NQ && n_super <= TAIL_INBLOCK_MAX_SUPER;
 }
 template <int K>
 static int run_tail_single(const TopkWs& L, char* ws, const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D, int k, float* out_s,
                            int64_t* out_i, int64_t idx_base, float tau_scale, int debug_drop, hipStream_t st) {
     const size_t smem = (((size_t)D * 2 + 15) & ~(size_t)15) + (size_t)K * GROUP_ROWS * 12;
-    const int64_t n_super = (L.n_groups + SUPER - 1) / SUPER;
     ProfScope psc(ARX_K_SEARCH_RESCORE, st);
-    const float* gmax = (const float*)(ws + L.gmax);
-    const uint32_t* aux = (const uint32_t*)(ws + L.aux);
-    unsigned long long* stats = (unsigned long long*)(ws + L.stats);
-    if (n_super <= 2 * 1024) {
-        auto kern = tail_single_kernel<K, 1024, 2>;
-        if (smem > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)kern, (int)smem));
-        kern<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale, debug_drop, stats);
-    } else {
-        auto kern = tail_single_kernel<K, 1024, TAIL_RS_MAX>;
-        if (smem > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)kern, (int)smem));
-        kern<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale, debug_drop, stats);
-    }
+    auto kern = tail_single_kernel<K, 1024, 1, true, false>;       // <= 1 024 super-groups: one candidate per lane (pass A zeroed the counters)
+    if (smem > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)kern, (int)smem));
+    kern<<<nq, 1024, smem, st>>>((const float*)(ws + L.gmax), (const uint32_t*)(ws + L.aux), L.ldg, L.n_groups, nullptr, nullptr, 0, Q, C, n_rows,
+                                 D, k, out_s, out_i, idx_base, tau_scale, debug_drop, (unsigned long long*)(ws + L.stats), nullptr, nullptr,
+                                 nullptr, nullptr, nullptr, nullptr);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -1644,6 +1784,7 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         int rc = ARX_OK;
         const bool use_i8 = index_i8 && nq <= P.i8_max_nq;          // arx_topk_options.i8_max_queries
         const bool single = tail_single_ok(use_i8, nq, n_rows) && !(P.flags & ARX_TOPK_NO_SINGLE_ROW_TAIL);
+        const bool i8_single = use_i8 && !(P.flags & ARX_TOPK_NO_SINGLE_ROW_TAIL);          // the int8 pipeline's first step, one row per selected group
         if (P.flags & ARX_TOPK_TAIL_ONLY) {
             // pass A of this batch ran in an earlier ARX_TOPK_SCAN_ONLY call on this workspace (the caller ordered the two streams)
         } else if (use_i8) {                           // pass A over the int8 representation: upper bounds instead of scores, everything after it unchanged
@@ -1670,15 +1811,16 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         if (!glds) {
             rc = nq <= 64 ? launch_groupmax<64, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)
                : nq <= 128 ? launch_groupmax<128, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)
-                           : launch_groupmax<256, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, nullptr, nullptr, st);
+                           : launch_groupmax<256, false>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st);
         } else
 #endif
             if (persistent_pass_ok(nq, n_rows, dim, P.flags))
-                rc = launch_groupmax_persistent<f16_t, false>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, gmax, nullptr, L.ldg, P.cu_limit, st);
+                rc = single ? launch_groupmax_persistent<f16_t, false, true>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, gmax, aux16, L.ldg, P.cu_limit, st, zs16)
+                            : launch_groupmax_persistent<f16_t, false>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, gmax, nullptr, L.ldg, P.cu_limit, st);
             else
             rc = nq <= 64 ? launch_groupmax<64, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)
                : nq <= 128 ? launch_groupmax<128, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)
-                           : launch_groupmax<256, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, nullptr, nullptr, st);
+                           : launch_groupmax<256, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st);
         }
         if (rc != ARX_OK) return rc;
         if (P.flags & ARX_TOPK_SCAN_ONLY) continue;
@@ -1686,7 +1828,9 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         int64_t* oi = out_ids + (int64_t)q0 * k;
         // rescore geometry (same-box A/B, r02): a 16-wave block per query is fastest while the blocks fit the chip at once
         // (0.10 vs 0.13 ms at <= 64 queries); 4-wave blocks, eight to a CU, when there are thousands (2.9 vs 5.4 ms per 10 k)
-        if (single) rc = k > 10 ? run_tail_single<KSEL_BIG>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st)
+        if (i8_single) rc = k > 10 ? run_i8_single<KSEL_BIG>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, q0 == 0)
+                                   : run_i8_single<KSEL_SMALL>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, q0 == 0);
+        else if (single) rc = k > 10 ? run_tail_single<KSEL_BIG>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st)
                                 : run_tail_single<KSEL_SMALL>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
         else if (k > 10) rc = run_select_rescore<KSEL_BIG, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
         else if (nq <= 128) rc = run_select_rescore<KSEL_SMALL, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);

@@ -350,6 +350,9 @@ def main():
     ap.add_argument("--d1024-rows", type=int, default=6_250_000,
                     help="configs[4]'s per-rank slice: rows of a dim-1024 shard searched on one GPU (N = 1 only; 0 = skip)")
     ap.add_argument("--search-queries", type=int, default=10_000)
+    ap.add_argument("--search-qbs", type=str, default="1,64,256,all",
+                    help="query-batch sizes of the configs[2] leg ('all' = --search-queries); a profiling pass narrows it so that a kernel's "
+                         "average duration in the rocprofv3 table is ONE workload's")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-query-leg", action="store_true",
                     help="skip search.encode_plus_search (its query-sized forwards launch the GEMM kernels on tiny problems: under rocprofv3 "
@@ -609,7 +612,8 @@ def main():
         corpus = fill_unit_rows(N, D, seed=7, device=dev, row_base=rank * N)
         queries = fill_unit_rows(nq_all, D, seed=11, device=dev)          # same on every rank
         idx = ShardIndex(corpus, idx_base=rank * N)
-        res = {f"Qb={min(qb, nq_all)}": time_search(idx, queries, qb, N, D) for qb in (1, 64, 256, nq_all)}
+        qbs = [nq_all if t == "all" else int(t) for t in args.search_qbs.split(",") if t]
+        res = {f"Qb={min(qb, nq_all)}": time_search(idx, queries, qb, N, D) for qb in qbs}
         # the same searches with the int8 pre-filter (ShardIndex(prefilter="int8"): first pass over an int8 copy of the rows that yields
         # upper bounds; identical exact answers).  The library's default policy takes the int8 pass at every Qb
         # (a per-index crossover is `ShardIndex(i8_max_queries=...)`, passed with each call: the library keeps no settings).
@@ -617,7 +621,7 @@ def main():
         if D % 128 == 0 and D <= 1024:
             idx8 = ShardIndex(corpus, idx_base=rank * N, prefilter="int8")
             res8 = {}
-            for qb in (1, 64, 256, nq_all):
+            for qb in qbs:
                 qb = min(qb, nq_all)
                 s8, i8 = idx8.search_distributed(queries[:qb], 10)
                 s16, i16 = idx.search_distributed(queries[:qb], 10)

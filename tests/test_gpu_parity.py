@@ -604,7 +604,7 @@ def test_single_row_tail_equals_full_group_rescoring(hip):
     NO = hip.TOPK_NO_SINGLE_ROW_TAIL
     rs = np.random.RandomState(12)
     cases = [(64 * 700 + 13, 256, 37, 10), (64 * 123 + 1, 128, 128, 32), (5, 128, 3, 10), (700, 384, 1, 10), (64 * 40, 768, 65, 32),
-             (256 * 1030 + 255, 128, 64, 10)]
+             (256 * 1030 + 255, 128, 64, 10), (64 * 300 + 9, 256, 200, 10), (64 * 90, 384, 256, 32), (64 * 16 * 2100 + 5, 128, 256, 10)]
     for n, d, nq, k in cases:
         Cm = SO.unit_rows_f16(n, d, 100 + n % 7); Q = SO.unit_rows_f16(nq, d, 200 + nq)
         if n > 5000:
@@ -639,6 +639,24 @@ def test_single_row_tail_equals_full_group_rescoring(hip):
     Ce = np.tile(SO.unit_rows_f16(1, 128, 1), (64 * 300 + 5, 1)); Qe = SO.unit_rows_f16(4, 128, 2)
     s, i = ShardIndex(torch.from_numpy(Ce).cuda()).search(torch.from_numpy(Qe).cuda(), 10)
     assert np.array_equal(i.cpu().numpy(), np.tile(np.arange(10), (4, 1)))
+    # the int8 pipeline's first step takes the same kernel in its COLLECT form (one row per selected group, the select kernel's lists in
+    # front of it): same rows as with every selected group rescored in full, narrow and wide query tiles, ragged shards, k = 10 / 32
+    for n, d, nq, k in ((64 * 700 + 13, 256, 37, 10), (64 * 333 + 37, 256, 200, 10), (64 * 401 + 63, 128, 1030, 32), (5, 128, 3, 10),
+                        (64 * 16 * 1100 + 7, 128, 64, 10)):
+        Cm = SO.unit_rows_f16(n, d, 300 + n % 5); Q = SO.unit_rows_f16(nq, d, 400 + nq)
+        if n > 5000:
+            for j, r in enumerate((17 * 64 + 3, 17 * 64 + 9, 17 * 64 + 31)):
+                v = Q[0].astype(np.float32) * (0.9 - 0.01 * j) + 0.05 * rs.standard_normal(d).astype(np.float32)
+                Cm[r] = (v / np.linalg.norm(v)).astype(np.float16)
+        ct, qd = torch.from_numpy(Cm).cuda(), torch.from_numpy(Q).cuda()
+        i8x = ShardIndex(ct, idx_base=3, prefilter="int8")
+        s, i = i8x.search(qd, k)
+        s0, i0 = i8x.search(qd, k, flags=NO)
+        assert torch.equal(i, i0) and torch.equal(s, s0), (n, d, nq, k)
+        sd, idd = i8x.search(qd, k, drop_best=1)                              # a forgotten group comes back through the candidate lists
+        assert torch.equal(idd, i) and torch.equal(sd, s)
+        if n >= k:
+            _assert_topk_valid(Cm, Q, s.cpu().numpy(), i.cpu().numpy(), k, idx_base=3, tol=2e-6)
     # a shard beyond 2 048 super-groups (the 16-candidates-per-lane instance of the kernel), ragged end
     big = SO.unit_rows_f16(64 * 16 * 2100 + 77, 128, 5); Qb = SO.unit_rows_f16(9, 128, 6)
     idx = ShardIndex(torch.from_numpy(big).cuda())

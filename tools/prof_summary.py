@@ -66,8 +66,47 @@ def traffic(pmc_json, out):
     print(json.dumps(res, indent=1))
 
 
+def mfma(pmc_json, stats_mds, out):
+    """Per-kernel matrix-pipe utilisation from ONE SQ counter pass (MI355X_MICROARCH.md: SQ_VALU_MFMA_BUSY_CYCLES counts cycles, summed
+    over the chip's 1 024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs; the wave-state counters count quad-cycles and are used as
+    fractions of SQ_WAVE_CYCLES only):  MFMA busy = (SQ_VALU_MFMA_BUSY_CYCLES / 1024) / (GRBM_GUI_ACTIVE / 8);
+    clock under the profiler = GRBM_GUI_ACTIVE / 8 / the kernel's duration in the un-countered stats pass (indicative: profiled runs clock lower)."""
+    import re
+    d = json.load(open(pmc_json))
+    dur = {}
+    for md in stats_mds:
+        for ln in open(md):
+            m = re.match(r"\| (.+?) \| (\d+) \| ([\d.]+) \| ([\d.]+) \|", ln)
+            if m:
+                dur[m.group(1).split("(")[0].strip()] = float(m.group(3))
+    rows = []
+    for k, c in d.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in c or "GRBM_GUI_ACTIVE" not in c:
+            continue
+        busy, act = c["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"], c["GRBM_GUI_ACTIVE"]["avg"]
+        if busy <= 0 or act <= 0:
+            continue
+        wc = c.get("SQ_WAVE_CYCLES", {}).get("avg", 0) or 1
+        us = next((v for n, v in dur.items() if n.startswith(k[:60]) or k.startswith(n[:60])), None)
+        rows.append((busy / 1024 / (act / 8), k, c["SQ_VALU_MFMA_BUSY_CYCLES"]["calls"], act / 8, us,
+                     c.get("SQ_WAIT_ANY", {}).get("avg", 0) / wc, c.get("SQ_WAIT_INST_ANY", {}).get("avg", 0) / wc,
+                     c.get("SQ_ACTIVE_INST_ANY", {}).get("avg", 0) / wc))
+    rows.sort(reverse=True)
+    with open(out, "w") as o:
+        o.write("MFMA utilisation per kernel: one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY "
+                "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE) over python3 bench.py (encode 5 steps + 10 M x 768 search, "
+                "Qb 64 / 256); matrix pipe busy = (MFMA_BUSY / 1024 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); wave states as fractions of SQ_WAVE_CYCLES\n\n"
+                "| kernel | calls | matrix pipe busy | kernel cycles (GUI_ACTIVE / 8) | avg us (stats pass) | waves parked (WAIT_ANY) | issue-stalled (WAIT_INST_ANY) | issuing (ACTIVE_INST_ANY) |\n"
+                "|---|---|---|---|---|---|---|---|\n")
+        for u, k, n, cyc, us, wa, wi, ai in rows:
+            o.write(f"| {short(k)} | {n} | {u:.3f} | {cyc:,.0f} | {'' if us is None else f'{us:.1f}'} | {wa:.2f} | {wi:.2f} | {ai:.2f} |\n")
+    print(f"{len(rows)} kernels with matrix work -> {out}")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3:-1], sys.argv[-1])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3])
