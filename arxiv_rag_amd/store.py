@@ -5,6 +5,7 @@
   layout of `4-embed/utils/save_embeddings_to_disk.py:15-80` (`embeddings_batch_%04d.npy`,
   `metadata_batch_%04d.json`, `index.json` with `num_batches`), with the same return value as that file's
   `load_embeddings_from_disk` (:82-117): `(embeddings [N, D], metadata list)`.
+* `save_embeddings_disk` writes that batched layout (byte-identical to the reference's writer).
 * `HipCollection` keeps this rank's rows in HBM as fp16 and answers `query(...)` in the shape of a Chroma
   collection (`ids`, `documents`, `metadatas`, `distances` per query), so code written against the collection the
   reference fills at GEN:404-424 ports over.  Distances are squared L2 (Chroma's default space), which on unit
@@ -38,6 +39,35 @@ def load_embeddings_from_disk(input_dir: str | Path, batch_index: Optional[int] 
     if emb.shape[0] != index.get("total_embeddings", emb.shape[0]):
         raise ValueError(f"{p}: index.json says {index['total_embeddings']} rows, embeddings.npy has {emb.shape[0]}")
     return emb, meta
+
+
+def save_embeddings_disk(chunks: Sequence[Dict], embeddings, output_dir: str | Path = "./embeddings_saved", batch_size: int = 10000) -> None:
+    """Writer of the BATCHED on-disk layout (`4-embed/utils/save_embeddings_to_disk.py:15-80`, the reference's alternative to the three
+    files GEN writes): `embeddings_batch_%04d.npy` (float64 — the reference's `.tolist()` round trip — [<= batch_size, D]),
+    `metadata_batch_%04d.json` (the GEN fields + `batch_index`, `batch_position`; indent 2, ensure_ascii=False) and `index.json`
+    (`total_embeddings`, `embedding_dimension`, `num_batches`, `batch_size`, `chunks` = every chunk's id or null).  Byte-identical to
+    what the reference's function writes (tests/golden/harness/expected_batched, produced by that function).  `embeddings`: anything
+    indexable by row ([N, D] array, memmap, list of rows); one batch is in memory at a time."""
+    out = Path(output_dir)
+    out.mkdir(parents=True, exist_ok=True)
+    n = len(embeddings)
+    num_batches = (n + batch_size - 1) // batch_size
+    dim = int(np.asarray(embeddings[0]).shape[0]) if n else 0
+    for i in range(num_batches):
+        a, b = i * batch_size, min((i + 1) * batch_size, n)
+        np.save(out / f"embeddings_batch_{i:04d}.npy", np.asarray(embeddings[a:b], dtype=np.float64))
+        meta = []
+        for j, ch in enumerate(chunks[a:b]):
+            m = ch.get("metadata", {})
+            meta.append({"chunk_id": ch.get("chunk_id", f"chunk_{a + j}"), "paper_id": m.get("paper_id"), "section": m.get("section"),
+                         "quality_score": m.get("quality_score"), "text": ch["text"], "text_length": len(ch["text"]),
+                         "batch_index": i, "batch_position": j})
+        with open(out / f"metadata_batch_{i:04d}.json", "w", encoding="utf-8") as fh:
+            json.dump(meta, fh, indent=2, ensure_ascii=False)
+    index = {"total_embeddings": n, "embedding_dimension": dim, "num_batches": num_batches, "batch_size": batch_size,
+             "chunks": [ch.get("chunk_id") for ch in chunks]}
+    with open(out / "index.json", "w", encoding="utf-8") as fh:
+        json.dump(index, fh, indent=2)
 
 
 class HipCollection:

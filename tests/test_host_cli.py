@@ -534,6 +534,27 @@ def test_per_rank_loading_opens_only_the_files_it_needs(tmp_path, monkeypatch):
     assert GEN.default_load_workers() == max(1, int(GEN.effective_cpus() * 0.8) // 8)
 
 
+def test_batched_layout_writer_bytes_match_reference_output(tmp_path):
+    """VERDICT r3 'missing' #4: the reference's ALTERNATE layout (4-embed/utils/save_embeddings_to_disk.py:15-80).  The fixture is what
+    the reference's own `save_embeddings_disk` wrote for the harness chunks with batch_size = 2 (tools/make_golden.py batched); our
+    writer must produce the same bytes, and our reader must read them back."""
+    from arxiv_rag_amd.store import load_embeddings_from_disk, save_embeddings_disk
+    fx = HARN
+    chunks = []
+    for f in GEN.list_chunk_files(fx / "input"):
+        chunks.extend(GEN.load_chunks_from_file(f, 0.9))
+    embs = np.load(fx / "input_embeddings_f32.npy")
+    save_embeddings_disk(chunks, list(embs), output_dir=tmp_path / "o", batch_size=2)
+    want = sorted((fx / "expected_batched").iterdir())
+    assert [f.name for f in want] == sorted(f.name for f in (tmp_path / "o").iterdir())
+    for f in want:
+        assert (tmp_path / "o" / f.name).read_bytes() == f.read_bytes(), f.name
+    e, m = load_embeddings_from_disk(tmp_path / "o")
+    assert e.dtype == np.float64 and np.array_equal(e, embs.astype(np.float64)) and [x["batch_position"] for x in m] == [0, 1, 0]
+    save_embeddings_disk(chunks, np.asarray(embs), output_dir=tmp_path / "o2", batch_size=10000)      # an array, one batch
+    assert (tmp_path / "o2" / "index.json").read_text().count('"num_batches": 1') == 1
+
+
 # ------------------------------------------------------------------ on-disk layouts -> loader (SURVEY §8f row 2)
 def test_load_embeddings_from_disk_both_layouts(tmp_path):
     """GEN layout (written by our writer, byte-checked above) and the batched layout of

@@ -28,6 +28,8 @@ _lib.prof_enable(False)
 p = _lib.prof_read()
 print(json.dumps({"chunks_per_s": round(K * B / dt, 1), **{k: round(v[0] / v[1], 4) for k, v in p.items() if v[1]}}))
 ''' % str(ROOT)
+if __name__ != "__main__":
+    sys.argv = sys.argv[:1]
 libs = [a for a in sys.argv[1:] if not a.startswith("--")]
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 3
 for r in range(rounds):

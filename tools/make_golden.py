@@ -258,6 +258,35 @@ def gen_harness():
     print("harness fixtures:", len(chunks), "chunks kept")
 
 
+def gen_harness_batched():
+    """The reference's ALTERNATE on-disk layout: its own `save_embeddings_disk` (4-embed/utils/save_embeddings_to_disk.py:15-80, extracted
+    by line range and run HERE) on the harness chunks with batch_size = 2 -> tests/golden/harness/expected_batched/* (two batches)."""
+    src = GEN.parents[1] / "utils" / "save_embeddings_to_disk.py"
+    if not src.exists() or not (GOLD / "harness" / "input_embeddings_f32.npy").exists():
+        print("reference or harness fixtures absent; skipping the batched-layout fixture"); return
+    from tqdm import tqdm
+    lines = src.read_text().splitlines(keepends=True)
+    ns = {"json": json, "np": np, "Path": Path, "List": list, "Dict": dict, "tqdm": tqdm}
+    exec(compile(_extract(lines, 15, 80), "save_embeddings_to_disk.py:15-80", "exec"), ns)
+    save_fn = ns["save_embeddings_disk"]
+    nsl = {"json": json, "np": np, "Path": Path, "List": list, "Dict": dict}
+    exec(compile(_extract(GEN.read_text().splitlines(keepends=True), 76, 92), "GEN:76-92", "exec"), nsl)
+    fx = GOLD / "harness"
+    chunks = []
+    for f in sorted(f for f in (fx / "input").rglob("*.json") if not f.name.startswith("._")):
+        chunks.extend(nsl["load_chunks_from_file"](f, min_quality=0.9))
+    embs = list(np.load(fx / "input_embeddings_f32.npy"))
+    out = fx / "expected_batched"
+    out.mkdir(exist_ok=True)
+    with tempfile.TemporaryDirectory() as td:
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            save_fn(chunks, embs, output_dir=td, batch_size=2)
+        for f in sorted(Path(td).iterdir()):
+            (out / f.name).write_bytes(f.read_bytes())
+    print("batched-layout fixture:", sorted(f.name for f in out.iterdir()))
+
+
 def gen_semantic():
     """Run the reference's own sentence split (:1275-1276) and grouping walk (:1542-1599, cosine helper :1601-1605)
     on synthetic sentences + embeddings; the encode in between is the GPU path and is not part of this fixture."""
@@ -311,4 +340,4 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "tables", "search", "harness", "semantic", "full"]
     for w in what:
         {"tiny": gen_tiny, "full": gen_full, "tables": gen_tables, "search": gen_search,
-         "harness": gen_harness, "adversarial": gen_adversarial, "semantic": gen_semantic}[w]()
+         "harness": gen_harness, "adversarial": gen_adversarial, "semantic": gen_semantic, "batched": gen_harness_batched}[w]()
