@@ -93,34 +93,34 @@ __device__ __forceinline__ void groupmax_epilogue_f16(const f32x4 (&acc)[NI][MI]
     store_query_row<MI, float>(gmax_row, gm, m_first, nq, lane);
 }
 
-// fp16 pass, small query batches (<= 128): beside the group maximum, the aux word (below) of the group — the position of the row that holds
-// the largest pass-A score and an upper bound on the pass-A score of every OTHER row of the group.  The tail kernel then reads ONE fp16 row
-// of a selected group (1.5 KB) instead of its 64 (98 KB) whenever that bound is below the query's threshold: on a 625 k-row shard the
-// rescoring of 12 x 64 rows per query — one CU pulling 1.2 MB — was 0.07 ms of a 0.26-ms batch (profiles/r03).  The arg-max travels in the
-// low 6 bits of each value's float image (63 ulp either way, covered by the 8e-6 inflation of the second bound); the group maximum
-// itself is taken from the untouched values, so the selection and the certificate see what they saw before.
+// fp16 pass, small query batches on small shards: beside the group maximum, the aux word (below) of the group — the position of the 4-ROW
+// BLOCK (rows j*16 + 4*(lane>>4) + 0..3: what one lane holds of one MFMA block) that contains the largest pass-A score, and an upper bound
+// on the pass-A score of every row of the group OUTSIDE that block.  The tail kernel then reads four consecutive fp16 rows of a selected
+// group (6 KB) instead of its 64 (98 KB) whenever that bound is below the query's threshold: on a 625 k-row shard the rescoring of
+// 12 x 64 rows per query — one CU pulling 1.2 MB — was 0.07 ms of a 0.26-ms batch (profiles/r03).  Granularity is the epilogue's price:
+// tracking the arg-max ROW (first version, profiles/r04/tail_single_row_ab.md) keys every accumulator value — 4 instructions per element
+// where the plain maximum takes 1 — and cost pass A 4 % at <= 64 queries and 10-17 % at 256; the 4-row block keys one value in four:
+// 9 % at 256 queries, still 4 % at <= 64 (there it is not the VALU work; profiles/r04/tail_block4_ab.jsonl).
+// The block's position travels in the low 6 bits of a value's float image (63 ulp either way, covered by the 8e-6 inflation of the
+// bound); the group maximum itself is taken from the untouched values, so the selection and the certificate see what they saw before.
 __device__ __forceinline__ uint32_t pack_aux(float ub2, int arg_row);
 template <int MI, int NI>
 __device__ __forceinline__ void groupmax_epilogue_f16_aux(const f32x4 (&acc)[NI][MI], float* __restrict__ gmax_row, uint32_t* __restrict__ aux_row,
                                                           int m_first, int nq, int lane) {
     float gm[MI];
     uint32_t ga[MI];
-    const int lrow = (lane >> 4) * 4;
+    const uint32_t lrow = (uint32_t)(lane >> 4) * 4u;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         float mx = -INFINITY, m1 = -INFINITY, m2 = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float u = acc[j][i][r];
-                mx = fmaxf(mx, u);
-                const float key = __uint_as_float((__float_as_uint(u) & ~63u) | (uint32_t)(j * 16 + r));
-                m2 = __builtin_amdgcn_fmed3f(m1, m2, key);
-                m1 = fmaxf(m1, key);
-            }
-        m1 = __uint_as_float(__float_as_uint(m1) | (uint32_t)lrow);
-        m2 = __uint_as_float(__float_as_uint(m2) | (uint32_t)lrow);
+        for (int j = 0; j < NI; ++j) {
+            const float bj = fmaxf(fmaxf(acc[j][i][0], acc[j][i][1]), fmaxf(acc[j][i][2], acc[j][i][3]));
+            mx = fmaxf(mx, bj);
+            const float key = __uint_as_float((__float_as_uint(bj) & ~63u) | ((uint32_t)(j * 16) + lrow));
+            m2 = __builtin_amdgcn_fmed3f(m1, m2, key);
+            m1 = fmaxf(m1, key);
+        }
         {
             float a1, b1, a2, b2;
             rows16(m1, a1, b1); rows16(m2, a2, b2);
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
 //   (4) top-k of the candidates; (5) certificate exactly as rescore_kernel's: U bounds every row in a group that was not selected; rows of a
 //       selected, unexpanded group other than its arg-max row have pass-A score <= ub2 < thr' <= thr (s_k only grows as rows are added),
 //       so they are covered too.  The fallback (every unscored group with gmax >= thr) is the same code.
-template <int K, int NT, int RS, bool INBLOCK, bool COLLECT>
+template <int K, int NT, int RS, bool INBLOCK, bool COLLECT, int CW>
 __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict__ gmax, const uint32_t* __restrict__ aux, int64_t ldg,
                                                           int64_t n_groups, const float* __restrict__ part_s, const int32_t* __restrict__ part_g,
                                                           int nslices, const f16_t* __restrict__ Q, const f16_t* __restrict__ C,
@@ -883,14 +883,16 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
     constexpr int NW = NT / 64;
     constexpr int K1 = K + 1;
     constexpr int KK = K1 > KMAX ? K1 : KMAX;
-    static_assert(3 * K >= NW && K <= 64, "fallback scratch / one lane per selected group");
+    // CW = rows per candidate block of a selected group: 1 (int8 pass: aux names the arg-max ROW) or 4 (fp16 pass: the arg-max 4-row block)
+    constexpr int NC = K * CW;
+    static_assert(3 * K >= NW && NC <= 64, "fallback scratch / one lane of wave 0 per candidate row");
     __shared__ float w_s[NW][KK];
     __shared__ int64_t w_i[NW][KK];
     __shared__ int32_t sel_g[K];
     __shared__ int64_t sel_row[K];
     __shared__ float sel_ub2[K];
-    __shared__ float cand_s[K];
-    __shared__ int64_t cand_i[K];
+    __shared__ float cand_s[NC];
+    __shared__ int64_t cand_i[NC];
     __shared__ int32_t exp_list[K];
     __shared__ float sh_u, sh_thr, sh_qn;
     __shared__ int sh_flag, sh_nexp;
@@ -994,8 +996,9 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
                 row = (int64_t)g * GROUP_ROWS + (int64_t)(a & 63u);
                 ub2 = __uint_as_float(a & 0xFFFF0000u);
                 // a position past the shard's end is a COPY of its last row (pass A clamps row addresses): then the copies tie with it and
-                // ub2 is its own score, so the group is expanded below; the candidate is the real row
-                row = row < n_rows ? row : n_rows - 1;
+                // ub2 is its own score, so the group is expanded below whenever that row matters; CW = 1: the candidate is the real row
+                // (CW = 4: rows past the end are skipped one by one)
+                if (CW == 1) row = row < n_rows ? row : n_rows - 1;
             }
             sel_row[lane] = row; sel_ub2[lane] = ub2;
         }
@@ -1005,22 +1008,23 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
         if (lane == 0) { sh_u = u; sh_qn = sqrtf(qq); }
     }
     __syncthreads();
-    // (3a) the K arg-max rows, exactly
+    // (3a) the K candidate blocks (CW rows each), exactly
     const int nch = D >> 3, l8 = lane & 7, rsub = lane >> 3;
-    for (int t0 = w * 8; t0 < K; t0 += NW * 8) {
-        const int t = t0 + rsub;
-        const bool ok = t < K && sel_g[t < K ? t : 0] >= 0;
-        const int64_t row = ok ? sel_row[t] : 0;
+    for (int t0 = w * 8; t0 < NC; t0 += NW * 8) {
+        const int t = t0 + rsub, tg = (t < NC ? t : 0) / CW;
+        const int64_t row0 = sel_row[tg] + (t % CW);
+        const bool ok = t < NC && sel_g[tg] >= 0 && row0 < n_rows;
+        const int64_t row = ok ? row0 : 0;
         const float a = exact_row_score(C + row * D, qs, nch, l8, ok);
-        if (l8 == 0 && t < K) { cand_s[t] = ok ? a : -INFINITY; cand_i[t] = ok ? row : -1; }
+        if (l8 == 0 && t < NC) { cand_s[t] = ok ? a : -INFINITY; cand_i[t] = ok ? row : -1; }
     }
     __syncthreads();
     if (w == 0) {
-        const float my = lane < K ? cand_s[lane] : -INFINITY;
-        const int64_t mi = lane < K ? cand_i[lane] : -1;
+        const float my = lane < NC ? cand_s[lane] : -INFINITY;
+        const int64_t mi = lane < NC ? cand_i[lane] : -1;
         int better = 0;
 #pragma unroll 4
-        for (int j = 0; j < K; ++j) {
+        for (int j = 0; j < NC; ++j) {
             const float sj = __shfl(my, j);
             const int64_t ij = __shfl(mi, j);
             better += (ij >= 0 && mi >= 0 && cand_better(sj, ij, my, mi)) ? 1 : 0;
@@ -1033,8 +1037,9 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
         const bool expand = lane < K && sel_g[lane < K ? lane : 0] >= 0 && (sel_ub2[lane < K ? lane : 0] >= thr0);
         const unsigned long long em = __ballot(expand);
         if (expand) exp_list[__popcll(em & ((1ull << lane) - 1ull))] = lane;
-        // an unexpanded group contributes its arg-max row: slot (group index, position 0)
-        if (lane < K && !expand && mi >= 0) { gs[lane * GROUP_ROWS] = my; gi_[lane * GROUP_ROWS] = mi; }
+        // an unexpanded group contributes its candidate block: slots (group index, 0 .. CW-1)
+        const int cg = (lane < NC ? lane : 0) / CW;
+        if (lane < NC && !((em >> cg) & 1ull) && mi >= 0) { gs[cg * GROUP_ROWS + lane % CW] = my; gi_[cg * GROUP_ROWS + lane % CW] = mi; }
         if (lane == 0) sh_nexp = __popcll(em);
         if (em == 0ull) {
             // the common case: the answer is the K candidates in rank order; nothing else to score
@@ -1055,7 +1060,7 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
             }
             if (flag) {                                          // the fallback starts from the sorted list in gs / gi_[0..k)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane < K) { gs[lane * GROUP_ROWS] = -INFINITY; gi_[lane * GROUP_ROWS] = -1; }
+                if (lane < NC) { gs[cg * GROUP_ROWS + lane % CW] = -INFINITY; gi_[cg * GROUP_ROWS + lane % CW] = -1; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (mi >= 0 && better < k) { gs[better] = my; gi_[better] = mi; }
             }
@@ -1617,10 +1622,10 @@ static int run_i8_single(const TopkWs& L, char* ws, const f16_t* Q, int nq, cons
         ARX_HIP_CHECK(hipGetLastError());
     }
     ProfScope psc(ARX_K_SEARCH_RESCORE, st);
-    auto k_in_c = tail_single_kernel<KSEL_SMALL, 1024, 1, true, true>;
-    auto k_in_r = tail_single_kernel<KSEL_SMALL, 1024, 1, true, false>;
-    auto k_pl_c = tail_single_kernel<K, 1024, R1, false, true>;
-    auto k_pl_r = tail_single_kernel<K, 1024, R1, false, false>;
+    auto k_in_c = tail_single_kernel<KSEL_SMALL, 1024, 1, true, true, 1>;
+    auto k_in_r = tail_single_kernel<KSEL_SMALL, 1024, 1, true, false, 1>;
+    auto k_pl_c = tail_single_kernel<K, 1024, R1, false, true, 1>;
+    auto k_pl_r = tail_single_kernel<K, 1024, R1, false, false, 1>;
     if (smem > 48 * 1024) {
         ARX_HIP_CHECK(arx_func_smem((const void*)(inblock ? k_in_c : k_pl_c), (int)smem));
         ARX_HIP_CHECK(arx_func_smem((const void*)(inblock ? k_in_r : k_pl_r), (int)smem));
@@ -1702,16 +1707,16 @@ static int run_select_rescore(const TopkWs& L, char* ws, const f16_t* Q, int nq,
 // hide); the tail saves 0.03 ms (<= 64 queries) to 0.08 ms (256) per batch.  Same box, same binary, arms interleaved
 // (profiles/r04/tail_single_row_ab.md): a win at 625 k rows for every batch size (0.228 against 0.258 ms at 64 queries), break-even at
 // 2 M rows, a loss beyond.  Hence: shards of up to TAIL_INBLOCK_MAX_SUPER super-groups (1 M rows).
-static bool tail_single_ok(bool use_i8, int nq, int64_t n_rows) {
+static bool tail_single_ok(bool use_i8, int nq, int64_t n_rows, int k) {
     const int64_t n_groups = (n_rows + GROUP_ROWS - 1) / GROUP_ROWS, n_super = (n_groups + SUPER - 1) / SUPER;
-    return !use_i8 && nq <= AUX16_MAX_NQ && n_super <= TAIL_INBLOCK_MAX_SUPER;
+    return !use_i8 && k <= 10 && nq <= AUX16_MAX_NQ && n_super <= TAIL_INBLOCK_MAX_SUPER;      // (k <= 10: 12 groups x 4 rows = one lane each)
 }
 template <int K>
 static int run_tail_single(const TopkWs& L, char* ws, const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D, int k, float* out_s,
                            int64_t* out_i, int64_t idx_base, float tau_scale, int debug_drop, hipStream_t st) {
     const size_t smem = (((size_t)D * 2 + 15) & ~(size_t)15) + (size_t)K * GROUP_ROWS * 12;
     ProfScope psc(ARX_K_SEARCH_RESCORE, st);
-    auto kern = tail_single_kernel<K, 1024, 1, true, false>;       // <= 1 024 super-groups: one candidate per lane (pass A zeroed the counters)
+    auto kern = tail_single_kernel<K, 1024, 1, true, false, 4>;    // <= 1 024 super-groups: one candidate per lane (pass A zeroed the counters)
     if (smem > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)kern, (int)smem));
     kern<<<nq, 1024, smem, st>>>((const float*)(ws + L.gmax), (const uint32_t*)(ws + L.aux), L.ldg, L.n_groups, nullptr, nullptr, 0, Q, C, n_rows,
                                  D, k, out_s, out_i, idx_base, tau_scale, debug_drop, (unsigned long long*)(ws + L.stats), nullptr, nullptr,
@@ -1783,7 +1788,7 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         float* gmax = (float*)((char*)ws + L.gmax);
         int rc = ARX_OK;
         const bool use_i8 = index_i8 && nq <= P.i8_max_nq;          // arx_topk_options.i8_max_queries
-        const bool single = tail_single_ok(use_i8, nq, n_rows) && !(P.flags & ARX_TOPK_NO_SINGLE_ROW_TAIL);
+        const bool single = tail_single_ok(use_i8, nq, n_rows, k) && !(P.flags & ARX_TOPK_NO_SINGLE_ROW_TAIL);
         const bool i8_single = use_i8 && !(P.flags & ARX_TOPK_NO_SINGLE_ROW_TAIL);          // the int8 pipeline's first step, one row per selected group
         if (P.flags & ARX_TOPK_TAIL_ONLY) {
             // pass A of this batch ran in an earlier ARX_TOPK_SCAN_ONLY call on this workspace (the caller ordered the two streams)
@@ -1830,8 +1835,7 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         // (0.10 vs 0.13 ms at <= 64 queries); 4-wave blocks, eight to a CU, when there are thousands (2.9 vs 5.4 ms per 10 k)
         if (i8_single) rc = k > 10 ? run_i8_single<KSEL_BIG>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, q0 == 0)
                                    : run_i8_single<KSEL_SMALL>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, q0 == 0);
-        else if (single) rc = k > 10 ? run_tail_single<KSEL_BIG>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st)
-                                : run_tail_single<KSEL_SMALL>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
+        else if (single) rc = run_tail_single<KSEL_SMALL>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st);
         else if (k > 10) rc = run_select_rescore<KSEL_BIG, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
         else if (nq <= 128) rc = run_select_rescore<KSEL_SMALL, 1024>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
         else rc = run_select_rescore<KSEL_SMALL, 256>(L, (char*)ws, Q, nq, C, n_rows, dim, k, os, oi, idx_base, tau_scale, debug_drop, st, use_i8, q0 == 0);
