@@ -1420,7 +1420,10 @@ __global__ __launch_bounds__(256) void fill_clustered_rows_kernel(f16_t* __restr
     const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (lrow >= n_rows) return;
     const int64_t row = lrow + row_base;
-    const uint64_t cl = splitmix64(seed ^ splitmix64(0xC105ull + (uint64_t)row)) % (uint64_t)n_clusters;
+    // n_clusters > 0: cluster = hash(row) (members scattered over the shard); n_clusters < 0: TOPIC ORDER — consecutive runs of -n_clusters rows
+    // share a centre (consecutive chunks of one paper: neighbours in row order AND in embedding space, so whole 64-row groups are near-tied)
+    const uint64_t cl = n_clusters > 0 ? splitmix64(seed ^ splitmix64(0xC105ull + (uint64_t)row)) % (uint64_t)n_clusters
+                                       : (uint64_t)row / (uint64_t)(-n_clusters);
     float v[16];
     float sq = 0.f;
     const int per = D / 64;
@@ -1933,8 +1936,8 @@ extern "C" int32_t arx_fill_clustered_rows_f16_at(void* dst, int64_t n_rows, int
                                                   float spread, int32_t n_hot_dims, float hot_gain, void* stream) {
     ARX_REQUIRE(dst && n_rows > 0 && row_base >= 0, "bad args");
     ARX_REQUIRE(dim % 128 == 0 && dim <= 1024, "dim=%d must be a multiple of 128, <= 1024", dim);
-    ARX_REQUIRE(n_clusters > 0 && n_clusters <= (1 << 20) && spread >= 0.f && n_hot_dims >= 0 && n_hot_dims <= 16 && hot_gain > 0.f,
-                "bad mixture parameters");
+    ARX_REQUIRE(n_clusters != 0 && n_clusters <= (1 << 20) && n_clusters >= -(1 << 20) && spread >= 0.f && n_hot_dims >= 0 && n_hot_dims <= 16 &&
+                hot_gain > 0.f, "bad mixture parameters");
     const int64_t blocks = (n_rows + 3) / 4;
     ARX_REQUIRE(blocks < (1ll << 31), "too many rows for one launch");
     fill_clustered_rows_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((f16_t*)dst, n_rows, dim, seed, row_base, n_clusters, spread,

@@ -349,7 +349,8 @@ def fill_clustered_rows(n_rows: int, dim: int, seed: int, n_clusters: int, devic
                         hot_dims: int = 3, hot_gain: float = 6.0) -> torch.Tensor:
     """Embedding-LIKE synthetic rows generated in HBM (`arx_fill_clustered_rows_f16_at`): tight clusters around `n_clusters` centres and a
     few hot dimensions — what the iid Gaussian rows of `fill_unit_rows` are not: a query's neighbours score within the int8 bound's
-    slack of each other, and max|x| (the int8 scale) is set by the hot dimensions.  Queries: same seed, a `row_base` beyond the corpus."""
+    slack of each other, and max|x| (the int8 scale) is set by the hot dimensions.  Queries: same seed, a `row_base` beyond the corpus
+    (scattered clusters) or inside it (topic order).  `n_clusters < 0`: TOPIC ORDER, consecutive runs of `-n_clusters` rows share a centre."""
     lib = _lib.load()
     t = torch.empty((n_rows, dim), dtype=torch.float16, device=device)
     if n_rows > 0:

@@ -276,7 +276,9 @@ int32_t arx_fill_unit_rows_f16_at(void* dst, int64_t n_rows, int32_t dim, uint64
  * hash(seed, r) % n_clusters and is centre(cluster) + spread * noise(r), both N(0,1) per dimension times a per-dimension gain that is
  * hot_gain on n_hot_dims dimensions chosen by the seed (outlier dimensions: they set max|x| and with it the int8 scale of every row)
  * and 1 elsewhere; L2-normalised, fp16.  Rows of the same seed share the centres whatever row_base is, so queries drawn with a
- * row_base beyond the corpus are new points of the same mixture.  dim % 128 == 0, dim <= 1024. */
+ * row_base beyond the corpus are new points of the same mixture.  n_clusters < 0 = TOPIC ORDER: cluster(r) = r / (-n_clusters), i.e.
+ * consecutive runs of -n_clusters rows share a centre (the chunks of one paper: neighbours in row order and in embedding space — whole
+ * 64-row groups of near-tied rows, the hard layout for group-max selection).  dim % 128 == 0, dim <= 1024. */
 int32_t arx_fill_clustered_rows_f16_at(void* dst, int64_t n_rows, int32_t dim, uint64_t seed, int64_t row_base, int32_t n_clusters,
                                        float spread, int32_t n_hot_dims, float hot_gain, void* stream);
 

@@ -665,6 +665,33 @@ def test_single_row_tail_equals_full_group_rescoring(hip):
     assert torch.equal(i, i0) and torch.equal(s, s0)
     _assert_topk_valid(big, Qb, s.cpu().numpy(), i.cpu().numpy(), 10)
 
+
+def test_search_topic_ordered_rows_whole_groups_near_tied(hip):
+    """The hard layout for group-max selection and for the 4-row tail: TOPIC ORDER (`fill_clustered_rows(n_clusters=-100)`: runs of 100
+    consecutive rows share a centre, as the chunks of one paper do), queries = corpus rows + noise.  A query's neighbours fill whole 64-row
+    groups with near-tied rows: the selected groups' second bounds reach the threshold and they must be EXPANDED; the int8 bound lets
+    whole runs through as (query, group) candidates.  Answers: exact, row by row against fp32 scores of every row — fp16 tail (small
+    shard: the 4-row path), the kernel pair (flag), int8, k = 10 and 32, 40 and 200 queries."""
+    from arxiv_rag_amd.index import ShardIndex, fill_clustered_rows
+    n, d = 64 * 2000 + 17, 256
+    ct = fill_clustered_rows(n, d, seed=5, n_clusters=-100)
+    assert torch.equal(fill_clustered_rows(1000, d, seed=5, n_clusters=-100, row_base=3000), ct[3000:4000])
+    run_cos = (ct[:100].float() @ ct[:100].float().T).mean().item(); far_cos = (ct[:100].float() @ ct[5000:5100].float().T).abs().mean().item()
+    assert run_cos > 0.8 and far_cos < 0.2                                    # rows of a run are neighbours, runs are unrelated
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    rows = torch.randint(0, n, (200,), generator=g, device="cuda")
+    q = torch.nn.functional.normalize(ct[rows].float() + 0.01 * torch.randn((200, d), generator=g, device="cuda"), dim=1).to(torch.float16)
+    Cm, Q = ct.cpu().numpy(), q.cpu().numpy()
+    idx, idx8 = ShardIndex(ct, idx_base=2), ShardIndex(ct, idx_base=2, prefilter="int8")
+    for nq, k in ((40, 10), (200, 10), (40, 32)):
+        s, i = idx.search(q[:nq], k)
+        _assert_topk_valid(Cm, Q[:nq], s.cpu().numpy(), i.cpu().numpy(), k, idx_base=2, tol=2e-6)
+        assert (i[:, 0] - 2 == rows[:nq]).float().mean() > 0.9                # (a query's own row leads unless a twin in its run beats it)
+        s0, i0 = idx.search(q[:nq], k, flags=hip.TOPK_NO_SINGLE_ROW_TAIL)
+        _assert_same_topk_up_to_ties(ct, q[:nq], (s, i), (s0, i0), idx_base=2)
+        s8, i8 = idx8.search(q[:nq], k)
+        _assert_topk_valid(Cm, Q[:nq], s8.cpu().numpy(), i8.cpu().numpy(), k, idx_base=2, tol=2e-6)
+
 def test_merge_kernel_exact(hip):
     from arxiv_rag_amd.index import merge_partials
     rs = np.random.RandomState(0)
