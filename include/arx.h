@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ARX_VERSION 100            /* 0.1.0 */
+#define ARX_VERSION 110            /* 0.1.1: search policy per call (arx_topk_options), no process-wide search state */
 
 #define ARX_OK            0
 #define ARX_ERR_ARG      -1        /* bad argument / unsupported shape */
