@@ -788,90 +788,96 @@ def main():
     # queries are new points of the same mixture.  Reported: QPS per Qb for the fp16 and int8 first passes, how often the certificate's slow
     # path ran, and what an `adaptive` index decides.
     if args.clustered_rows > 0 and world == 1:
-        from arxiv_rag_amd.index import fill_clustered_rows
-        Nc, Dc = args.clustered_rows, cfg.hidden
-        ncl = max(16, Nc // 500)
-        cc = fill_clustered_rows(Nc, Dc, seed=21, n_clusters=ncl, device=dev)
-        qc = fill_clustered_rows(2048, Dc, seed=21, n_clusters=ncl, device=dev, row_base=1 << 40)
-        ic = ShardIndex(cc)
-        rc16 = {}
-        for qb in (1, 64, 256):
-            e = time_search(ic, qc, qb, Nc, Dc)
-            ic.search(qc[:qb], 10)
-            fl, ex = ic.certificate_stats()
-            e["certificate"] = {"queries_on_the_slow_path": fl, "extra_groups_rescored": ex, "of_queries": qb}
-            rc16[f"Qb={qb}"] = e
-        rc8, adaptive = None, None
-        if Dc % 128 == 0 and Dc <= 1024:
-            ic8 = ShardIndex(cc, prefilter="int8")
-            rc8 = {}
+        try:                                                   # an extra leg: its failure must not cost the bench line
+            from arxiv_rag_amd.index import fill_clustered_rows
+            Nc, Dc = args.clustered_rows, cfg.hidden
+            ncl = max(16, Nc // 500)
+            cc = fill_clustered_rows(Nc, Dc, seed=21, n_clusters=ncl, device=dev)
+            qc = fill_clustered_rows(2048, Dc, seed=21, n_clusters=ncl, device=dev, row_base=1 << 40)
+            ic = ShardIndex(cc)
+            rc16 = {}
             for qb in (1, 64, 256):
-                e = time_search(ic8, qc, qb, Nc, Dc, int8_bytes=True)
-                s8, i8 = ic8.search(qc[:qb], 10)
-                fl, ex = ic8.certificate_stats()
-                s16, i16 = ic.search(qc[:qb], 10)
-                e["certificate"] = {"queries_overflowed_to_the_exhaustive_kernel": fl, "candidate_pairs": ex, "of_queries": qb}
-                e["rows_identical_to_fp16_pass"] = float((i8 == i16).all(dim=1).float().mean().item())
-                e["speedup_vs_fp16_pass"] = round(e["qps"] / rc16[f"Qb={qb}"]["qps"], 3)
-                rc8[f"Qb={qb}"] = e
-            ia = ShardIndex(cc, prefilter="int8", adaptive=True)
-            for _ in range(4):
-                ia.search(qc[:64], 10)
-            adaptive = {"prefilter_switched_off": bool(ia.prefilter_disabled)}
-            del ic8, ia
-        # the HARD layout: topic order — runs of 500 consecutive rows share a centre (the chunks of one paper), so a query's neighbours fill whole
-        # 64-row groups with near-tied rows: every selected group expands, the int8 bound lets whole runs through
-        topic = None
-        try:
-            ct_ = fill_clustered_rows(Nc, Dc, seed=22, n_clusters=-500, device=dev)
-            qrows = torch.randint(0, Nc, (2048,), device=dev)
-            # a query = a NEW point near a random corpus row's run: that row + isotropic noise (generator with spread 1, no hot dimensions), renormalised
-            qt_ = ct_[qrows].clone()
-            noise = fill_clustered_rows(2048, Dc, seed=23, n_clusters=1 << 20, device=dev, spread=1.0, hot_dims=0)
-            qt_ = torch.nn.functional.normalize(qt_.float() + 0.15 * noise.float(), dim=1).to(torch.float16)
-            it_ = ShardIndex(ct_)
-            topic = {"fp16_pass": {}, "int8_prefilter": {}}
-            for qb in (64, 256):
-                e = time_search(it_, qt_, qb, Nc, Dc)
-                it_.search(qt_[:qb], 10); fl, ex = it_.certificate_stats()
+                e = time_search(ic, qc, qb, Nc, Dc)
+                ic.search(qc[:qb], 10)
+                fl, ex = ic.certificate_stats()
                 e["certificate"] = {"queries_on_the_slow_path": fl, "extra_groups_rescored": ex, "of_queries": qb}
-                topic["fp16_pass"][f"Qb={qb}"] = e
-            it8 = ShardIndex(ct_, prefilter="int8")
-            for qb in (64, 256):
-                e = time_search(it8, qt_, qb, Nc, Dc, int8_bytes=True)
-                s8, i8 = it8.search(qt_[:qb], 10); fl, ex = it8.certificate_stats()
-                s16, i16 = it_.search(qt_[:qb], 10)
-                e["certificate"] = {"queries_overflowed_to_the_exhaustive_kernel": fl, "candidate_pairs": ex, "of_queries": qb}
-                e["scores_identical_to_fp16_pass"] = bool(torch.equal(s8, s16))
-                e["speedup_vs_fp16_pass"] = round(e["qps"] / topic["fp16_pass"][f"Qb={qb}"]["qps"], 3)
-                topic["int8_prefilter"][f"Qb={qb}"] = e
-            ia_ = ShardIndex(ct_, prefilter="int8", adaptive=True)
-            for _ in range(4):
-                ia_.search(qt_[:64], 10)
-            topic["adaptive_index"] = {"prefilter_switched_off": bool(ia_.prefilter_disabled)}
-            s_, i_ = it_.search(qt_[:8], 10)
-            full_t = torch.cat([qt_[:8].float() @ ct_[a:a + 1_000_000].float().T for a in range(0, Nc, 1_000_000)], dim=1)
-            topic["top10_scores_equal_fp32_reference_on_8_queries"] = bool(((full_t.topk(10, dim=1).values - s_).abs().max() < 1e-5).item())
-            topic["workload"] = (f"{Nc} x {Dc} rows in TOPIC ORDER: runs of 500 consecutive rows share a centre (spread 0.35, 3 hot dimensions); a query = a "
-                                 f"corpus row + 0.15 x unit noise, renormalised")
-            del it_, it8, ia_, ct_, qt_, full_t, noise
+                rc16[f"Qb={qb}"] = e
+            rc8, adaptive = None, None
+            if Dc % 128 == 0 and Dc <= 1024:
+                ic8 = ShardIndex(cc, prefilter="int8")
+                rc8 = {}
+                for qb in (1, 64, 256):
+                    e = time_search(ic8, qc, qb, Nc, Dc, int8_bytes=True)
+                    s8, i8 = ic8.search(qc[:qb], 10)
+                    fl, ex = ic8.certificate_stats()
+                    s16, i16 = ic.search(qc[:qb], 10)
+                    e["certificate"] = {"queries_overflowed_to_the_exhaustive_kernel": fl, "candidate_pairs": ex, "of_queries": qb}
+                    e["rows_identical_to_fp16_pass"] = float((i8 == i16).all(dim=1).float().mean().item())
+                    e["speedup_vs_fp16_pass"] = round(e["qps"] / rc16[f"Qb={qb}"]["qps"], 3)
+                    rc8[f"Qb={qb}"] = e
+                ia = ShardIndex(cc, prefilter="int8", adaptive=True)
+                for _ in range(4):
+                    ia.search(qc[:64], 10)
+                adaptive = {"prefilter_switched_off": bool(ia.prefilter_disabled)}
+                del ic8, ia
+            # the HARD layout: topic order — runs of 500 consecutive rows share a centre (the chunks of one paper), so a query's neighbours fill whole
+            # 64-row groups with near-tied rows: every selected group expands, the int8 bound lets whole runs through
+            topic = None
+            try:
+                ct_ = fill_clustered_rows(Nc, Dc, seed=22, n_clusters=-500, device=dev)
+                qrows = torch.randint(0, Nc, (2048,), device=dev)
+                # a query = a NEW point near a random corpus row's run: that row + isotropic noise (generator with spread 1, no hot dimensions), renormalised
+                qt_ = ct_[qrows].clone()
+                noise = fill_clustered_rows(2048, Dc, seed=23, n_clusters=1 << 20, device=dev, spread=1.0, hot_dims=0)
+                qt_ = torch.nn.functional.normalize(qt_.float() + 0.15 * noise.float(), dim=1).to(torch.float16)
+                it_ = ShardIndex(ct_)
+                topic = {"fp16_pass": {}, "int8_prefilter": {}}
+                for qb in (64, 256):
+                    e = time_search(it_, qt_, qb, Nc, Dc)
+                    it_.search(qt_[:qb], 10); fl, ex = it_.certificate_stats()
+                    e["certificate"] = {"queries_on_the_slow_path": fl, "extra_groups_rescored": ex, "of_queries": qb}
+                    topic["fp16_pass"][f"Qb={qb}"] = e
+                it8 = ShardIndex(ct_, prefilter="int8")
+                for qb in (64, 256):
+                    e = time_search(it8, qt_, qb, Nc, Dc, int8_bytes=True)
+                    s8, i8 = it8.search(qt_[:qb], 10); fl, ex = it8.certificate_stats()
+                    s16, i16 = it_.search(qt_[:qb], 10)
+                    e["certificate"] = {"queries_overflowed_to_the_exhaustive_kernel": fl, "candidate_pairs": ex, "of_queries": qb}
+                    e["scores_identical_to_fp16_pass"] = bool(torch.equal(s8, s16))
+                    e["speedup_vs_fp16_pass"] = round(e["qps"] / topic["fp16_pass"][f"Qb={qb}"]["qps"], 3)
+                    topic["int8_prefilter"][f"Qb={qb}"] = e
+                ia_ = ShardIndex(ct_, prefilter="int8", adaptive=True)
+                for _ in range(4):
+                    ia_.search(qt_[:64], 10)
+                topic["adaptive_index"] = {"prefilter_switched_off": bool(ia_.prefilter_disabled)}
+                s_, i_ = it_.search(qt_[:8], 10)
+                full_t = torch.cat([qt_[:8].float() @ ct_[a:a + 1_000_000].float().T for a in range(0, Nc, 1_000_000)], dim=1)
+                topic["top10_scores_equal_fp32_reference_on_8_queries"] = bool(((full_t.topk(10, dim=1).values - s_).abs().max() < 1e-5).item())
+                topic["workload"] = (f"{Nc} x {Dc} rows in TOPIC ORDER: runs of 500 consecutive rows share a centre (spread 0.35, 3 hot dimensions); a query = a "
+                                     f"corpus row + 0.15 x unit noise, renormalised")
+                del it_, it8, ia_, ct_, qt_, full_t, noise
+                torch.cuda.empty_cache()
+            except Exception as ex_:                                   # noqa: BLE001
+                topic = {"error": repr(ex_)[:300]}
+            # exactness on a subset, against the fp32 scores of every row (device fp32 matmul of the same fp16 values, 8 queries)
+            s_, i_ = ic.search(qc[:8], 10)
+            full = qc[:8].float() @ cc.float().T if Nc <= 2_000_000 else torch.cat([qc[:8].float() @ cc[a:a + 1_000_000].float().T
+                                                                                     for a in range(0, Nc, 1_000_000)], dim=1)
+            ref = full.topk(10, dim=1)
+            ok = bool(((ref.values - s_).abs().max() < 1e-5).item())
+            if search is None:
+                search = {}
+            search["clustered"] = {"workload": f"{Nc} x {Dc} fp16 rows in {ncl} clusters (spread 0.35) with 3 hot dimensions (gain 6), unit-normalised, "
+                                               f"generated in HBM (arx_fill_clustered_rows_f16_at); 2048 queries from the same mixture; k=10",
+                                   "fp16_pass": rc16, "int8_prefilter": rc8, "adaptive_index": adaptive, "topic_order": topic,
+                                   "top10_scores_equal_fp32_reference_on_8_queries": ok}
+            del ic, cc, qc, full
             torch.cuda.empty_cache()
         except Exception as ex_:                                   # noqa: BLE001
-            topic = {"error": repr(ex_)[:300]}
-        # exactness on a subset, against the fp32 scores of every row (device fp32 matmul of the same fp16 values, 8 queries)
-        s_, i_ = ic.search(qc[:8], 10)
-        full = qc[:8].float() @ cc.float().T if Nc <= 2_000_000 else torch.cat([qc[:8].float() @ cc[a:a + 1_000_000].float().T
-                                                                                 for a in range(0, Nc, 1_000_000)], dim=1)
-        ref = full.topk(10, dim=1)
-        ok = bool(((ref.values - s_).abs().max() < 1e-5).item())
-        if search is None:
-            search = {}
-        search["clustered"] = {"workload": f"{Nc} x {Dc} fp16 rows in {ncl} clusters (spread 0.35) with 3 hot dimensions (gain 6), unit-normalised, "
-                                           f"generated in HBM (arx_fill_clustered_rows_f16_at); 2048 queries from the same mixture; k=10",
-                               "fp16_pass": rc16, "int8_prefilter": rc8, "adaptive_index": adaptive, "topic_order": topic,
-                               "top10_scores_equal_fp32_reference_on_8_queries": ok}
-        del ic, cc, qc, full
-        torch.cuda.empty_cache()
+            if search is None:
+                search = {}
+            search["clustered"] = {"error": repr(ex_)[:300]}
+            torch.cuda.empty_cache()
 
     # ---- e2e_rank_slice (configs[3]'s real flow, one rank's share): the rows the ENCODER wrote during the sustained leg (the first
     # --e2e-rows of them, still in HBM) are searched where they lie, by queries the encoder also wrote, through search_distributed (RCCL
@@ -879,46 +885,50 @@ def main():
     # the worst case for the certificate; `certificate` says what it costs.
     e2e = None
     if e2e_rows is not None:
-        n_e, D_e = e2e_rows.shape
-        gq = torch.Generator(device=dev); gq.manual_seed(777)
-        nq_e = min(args.search_queries, 10_000)
-        qe = torch.empty((nq_e, D_e), dtype=torch.float16, device=dev)
-        for a in range(0, nq_e, B):
-            nrow = min(B, nq_e - a)
-            qids = torch.randint(4, cfg.vocab_size - 1, (nrow, S), generator=gq, device=dev, dtype=torch.int32)
-            qids[:, 0] = 0; qids[:, S - 1] = 2
-            enc.forward_tokens(qids, lens[:nrow], S, nrow * S, out=None, out_f16=qe[a:a + nrow], normalize=True)
-        ie = ShardIndex(e2e_rows, idx_base=rank * n_e)
-        res_e = {}
-        for qb in (64, 256, nq_e):
-            qb = min(qb, nq_e)
-            e = time_search(ie, qe, qb, n_e, D_e, pipelined=qb < nq_e)
-            ie.search(qe[:min(qb, 1024)], 10)
-            fl, ex = ie.certificate_stats()
-            e["certificate"] = {"queries_on_the_slow_path": fl, "extra_groups_rescored": ex, "of_queries": min(qb, 1024)}
-            res_e[f"Qb={qb}"] = e
-        pair_cos = float((e2e_rows[:2048].float() @ e2e_rows[2048:4096].float().T).mean().item())
-        chk = None
-        if rank == 0:
-            try:                                                 # exactness vs the oracle (CPU, fp32 on the same fp16 values), 8 queries
-                from oracle import search_oracle as SO
-                ms_, mi_ = ie.search(qe[:8], 10)
-                rs_, ri_ = SO.topk_search(e2e_rows.cpu().numpy(), qe[:8].cpu().numpy(), 11, idx_base=rank * n_e)
-                got = mi_.cpu().numpy()
-                bad = 0
-                for qq in range(8):
-                    if set(got[qq].tolist()) != set(ri_[qq, :10].tolist()) and not (rs_[qq, 9] - rs_[qq, 10] < 1e-6):
-                        bad += 1
-                chk = {"queries": 8, "top10_sets_equal_oracle": bad == 0,
-                       "max_abs_score_diff": float(np.abs(ms_.cpu().numpy() - rs_[:, :10]).max())}
-            except Exception as ex_:                               # noqa: BLE001
-                chk = {"error": repr(ex_)[:200]}
-        e2e = {"workload": f"{n_e} x {D_e} fp16 rows written by the encoder in the sustained leg (rank {rank}'s slice, never left HBM), {nq_e} queries "
-                           f"encoded by the same forward ({S} token ids each), top-10 through search_distributed; world {world}",
-               "encode_chunks_per_s": None if sustained is None else sustained["chunks_per_s"], "results": res_e,
-               "mean_cosine_between_random_rows": round(pair_cos, 4), "vs_oracle": chk}
-        del ie, e2e_rows, qe
-        torch.cuda.empty_cache()
+        try:                                                   # an extra leg: its failure must not cost the bench line
+            n_e, D_e = e2e_rows.shape
+            gq = torch.Generator(device=dev); gq.manual_seed(777)
+            nq_e = min(args.search_queries, 10_000)
+            qe = torch.empty((nq_e, D_e), dtype=torch.float16, device=dev)
+            for a in range(0, nq_e, B):
+                nrow = min(B, nq_e - a)
+                qids = torch.randint(4, cfg.vocab_size - 1, (nrow, S), generator=gq, device=dev, dtype=torch.int32)
+                qids[:, 0] = 0; qids[:, S - 1] = 2
+                enc.forward_tokens(qids, lens[:nrow], S, nrow * S, out=None, out_f16=qe[a:a + nrow], normalize=True)
+            ie = ShardIndex(e2e_rows, idx_base=rank * n_e)
+            res_e = {}
+            for qb in (64, 256, nq_e):
+                qb = min(qb, nq_e)
+                e = time_search(ie, qe, qb, n_e, D_e, pipelined=qb < nq_e)
+                ie.search(qe[:min(qb, 1024)], 10)
+                fl, ex = ie.certificate_stats()
+                e["certificate"] = {"queries_on_the_slow_path": fl, "extra_groups_rescored": ex, "of_queries": min(qb, 1024)}
+                res_e[f"Qb={qb}"] = e
+            pair_cos = float((e2e_rows[:2048].float() @ e2e_rows[2048:4096].float().T).mean().item())
+            chk = None
+            if rank == 0:
+                try:                                                 # exactness vs the oracle (CPU, fp32 on the same fp16 values), 8 queries
+                    from oracle import search_oracle as SO
+                    ms_, mi_ = ie.search(qe[:8], 10)
+                    rs_, ri_ = SO.topk_search(e2e_rows.cpu().numpy(), qe[:8].cpu().numpy(), 11, idx_base=rank * n_e)
+                    got = mi_.cpu().numpy()
+                    bad = 0
+                    for qq in range(8):
+                        if set(got[qq].tolist()) != set(ri_[qq, :10].tolist()) and not (rs_[qq, 9] - rs_[qq, 10] < 1e-6):
+                            bad += 1
+                    chk = {"queries": 8, "top10_sets_equal_oracle": bad == 0,
+                           "max_abs_score_diff": float(np.abs(ms_.cpu().numpy() - rs_[:, :10]).max())}
+                except Exception as ex_:                               # noqa: BLE001
+                    chk = {"error": repr(ex_)[:200]}
+            e2e = {"workload": f"{n_e} x {D_e} fp16 rows written by the encoder in the sustained leg (rank {rank}'s slice, never left HBM), {nq_e} queries "
+                               f"encoded by the same forward ({S} token ids each), top-10 through search_distributed; world {world}",
+                   "encode_chunks_per_s": None if sustained is None else sustained["chunks_per_s"], "results": res_e,
+                   "mean_cosine_between_random_rows": round(pair_cos, 4), "vs_oracle": chk}
+            del ie, e2e_rows, qe
+            torch.cuda.empty_cache()
+        except Exception as ex_:                                   # noqa: BLE001
+            e2e = {"error": repr(ex_)[:300]}
+            torch.cuda.empty_cache()
 
     # ---- configs[4]'s encode half in the precision that is feasible (fp8: measured infeasible at the 1e-3 bar): bge-large shape
     # (24 L / 1024 / 16 heads / FFN 4096, CLS pool), bf16, 256 chunks x 256 tokens per step

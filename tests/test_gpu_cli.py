@@ -247,7 +247,8 @@ def test_bench_starts_its_own_rank_and_prints_one_json_line(hip):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["ARX_BENCH_FORCE_LAUNCH"] = "1"
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "64",
-                        "--sustained-chunks", "0", "--no-cpu-baseline", "--no-query-leg", "--search-rows", "200000",
+                        "--sustained-chunks", "4096", "--e2e-rows", "3000", "--clustered-rows", "0", "--bge-steps", "0",
+                        "--no-cpu-baseline", "--no-query-leg", "--search-rows", "200000",
                         "--search-total-rows", "100000", "--d1024-rows", "0", "--search-queries", "300"],
                        env=env, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -257,3 +258,7 @@ def test_bench_starts_its_own_rank_and_prints_one_json_line(hip):
     st = d["search"]["strong_scaling"]
     assert st["merged_vs_single_index"] == {"queries": 64, "ids_equal": True, "scores_equal": True}
     assert "allgather_plus_merge_ms" in st["results"]["Qb=64"] and st["results"]["Qb=64"]["qps_pipelined"] > 0
+    # round 4: the launch self-checks ran under the real process group, and the rows the encoder wrote were searched through it
+    assert d["launch"]["backend"] == "nccl" and d["launch"]["ranks_seen"] == [0] and d["launch"]["row_spans"] == [[0, 100000]]
+    e2e = d["e2e_rank_slice"]
+    assert "error" not in e2e and e2e["vs_oracle"]["top10_sets_equal_oracle"] is True and e2e["results"]["Qb=64"]["qps_pipelined"] > 0
