@@ -262,3 +262,40 @@ def test_bench_starts_its_own_rank_and_prints_one_json_line(hip):
     assert d["launch"]["backend"] == "nccl" and d["launch"]["ranks_seen"] == [0] and d["launch"]["row_spans"] == [[0, 100000]]
     e2e = d["e2e_rank_slice"]
     assert "error" not in e2e and e2e["vs_oracle"]["top10_sets_equal_oracle"] is True and e2e["results"]["Qb=64"]["qps_pipelined"] > 0
+
+
+def test_cli_init_distributed_nccl_with_gloo_host_group(hip, tmp_path):
+    """ADVICE r3 (high), the part a CPU test cannot reach: `init_distributed()` on a GPU box — device bound BEFORE the RCCL group exists,
+    `device_id` passed — and `host_group()`: a gloo group beside the nccl one, carrying the loader's `all_gather_object` without touching
+    device memory.  One rank (the only GPU here), in a child process with a clean environment; then the script's whole multi-rank branch
+    runs under it (per-rank loading -> encode -> fragment join)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    from tests.helpers import make_chunk_tree
+    make_chunk_tree(tmp_path / "in", n_files=5, chunks_per_file=4, seed=2)
+    code = r"""
+import os, sys
+sys.path.insert(0, os.environ["ARX_ROOT"])
+import torch, torch.distributed as dist
+from arxiv_rag_amd import generate_embeddings_parallel as GEN
+assert not dist.is_initialized()
+GEN.init_distributed()
+assert dist.get_backend() == "nccl" and torch.cuda.current_device() == 0
+hg = GEN.host_group()
+assert hg is not None and dist.get_backend(hg) == "gloo"
+out = [None]
+dist.all_gather_object(out, {"files": [3, 1, 4]}, group=hg)
+assert out == [{"files": [3, 1, 4]}]
+rc = GEN.load_chunks_for_rank(os.environ["ARX_IN"], 0.0, 2, 7, 1, 0)          # the count exchange over the host group
+assert (rc.lo, rc.hi, rc.total) == (0, 20, 20)
+t = torch.ones(4, device="cuda"); dist.all_reduce(t); assert t.sum().item() == 4   # and the nccl group works
+dist.barrier(); dist.destroy_process_group()
+print("INIT_OK")
+"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ARX_ROOT=str(root), ARX_IN=str(tmp_path / "in"), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "INIT_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
