@@ -1791,7 +1791,9 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         float* gmax = (float*)((char*)ws + L.gmax);
         int rc = ARX_OK;
         const bool use_i8 = index_i8 && nq <= P.i8_max_nq;          // arx_topk_options.i8_max_queries
-        const bool single = tail_single_ok(use_i8, nq, n_rows, k) && !(P.flags & ARX_TOPK_NO_SINGLE_ROW_TAIL);
+        // (decided on the CALL's query count, like the workspace layout: a call of more than 1 024 queries whose last internal pass is small
+        // has no aux region to write — found by tools/search_soak.py as a memory fault, 1 100 queries on a 100 k-row shard)
+        const bool single = tail_single_ok(use_i8, n_queries, n_rows, k) && !(P.flags & ARX_TOPK_NO_SINGLE_ROW_TAIL);
         const bool i8_single = use_i8 && !(P.flags & ARX_TOPK_NO_SINGLE_ROW_TAIL);          // the int8 pipeline's first step, one row per selected group
         if (P.flags & ARX_TOPK_TAIL_ONLY) {
             // pass A of this batch ran in an earlier ARX_TOPK_SCAN_ONLY call on this workspace (the caller ordered the two streams)

@@ -207,7 +207,7 @@ class ShardIndex:
         self._refresh()                                      # on the caller's stream, BEFORE any lane may read the int8 copy / norm bound
         lanes = max(1, min(int(lanes), len(batches)))
         pipe = self._pipeline(tail_cus, lanes)
-        need = self.workspace_bytes(max(q.shape[0] for q in batches), k)
+        need = max(self.workspace_bytes(nq_b, k) for nq_b in {q.shape[0] for q in batches})      # (not monotonic in the batch size: small batches carry aux words)
         for j in range(lanes):
             if pipe["ws"][j] is None or pipe["ws"][j].numel() < need:
                 pipe["ws"][j] = torch.empty(need, dtype=torch.uint8, device=dev)

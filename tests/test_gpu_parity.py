@@ -692,6 +692,25 @@ def test_search_topic_ordered_rows_whole_groups_near_tied(hip):
         s8, i8 = idx8.search(q[:nq], k)
         _assert_topk_valid(Cm, Q[:nq], s8.cpu().numpy(), i8.cpu().numpy(), k, idx_base=2, tol=2e-6)
 
+
+def test_more_than_1024_queries_with_a_small_last_pass_on_a_small_shard(hip):
+    """Found by tools/search_soak.py (a GPU memory fault): 1 100 queries = internal passes of 1 024 + 76 on a shard small enough for the
+    aux-word tail.  The tail choice must follow the CALL's query count (as the workspace layout does): a wide call reserves no aux region,
+    so its small last pass must not write one.  fp16 and int8, checked row by row, and the workspace sizing of `search_many` with batches on
+    both sides of the 256-query boundary."""
+    from arxiv_rag_amd.index import ShardIndex
+    Cm = SO.unit_rows_f16(64 * 1500 + 11, 128, 61)
+    ct = torch.from_numpy(Cm).cuda()
+    for nq in (1100, 1024 + 256, 2048 + 1):
+        Q = SO.unit_rows_f16(nq, 128, 62)
+        qd = torch.from_numpy(Q).cuda()
+        for pre in (None, "int8"):
+            idx = ShardIndex(ct, idx_base=5, prefilter=pre)
+            s, i = idx.search(qd, 10)
+            _assert_topk_valid(Cm, Q, s.cpu().numpy(), i.cpu().numpy(), 10, idx_base=5, tol=2e-6)
+            got = idx.search_many([qd[:256], qd[256:513], qd[513:1100]], 10)
+            assert torch.equal(torch.cat([x[1] for x in got]), i[:1100]) and torch.equal(torch.cat([x[0] for x in got]), s[:1100])
+
 def test_merge_kernel_exact(hip):
     from arxiv_rag_amd.index import merge_partials
     rs = np.random.RandomState(0)
