@@ -171,8 +171,9 @@ int32_t arx_topk_search_i8(const void* corpus, const void* index_i8, int64_t n_r
 /* Per-CALL policy of a search (nothing here is remembered by the library: two indices with different policies can be searched from two
  * host threads at once).  Zero-initialise, set struct_bytes = sizeof(arx_topk_options), fill what differs from the defaults. */
 #define ARX_TOPK_NO_PERSISTENT 1   /* flags: take the per-tile pass-A kernel even where the persistent one applies (A/B measurements) */
-#define ARX_TOPK_NO_SINGLE_ROW_TAIL 8 /* flags: small fp16 batches take the select + rescore kernel pair (all 64 rows of each selected group) instead of
-                                      the single-kernel tail that rescoring only each group's arg-max row (A/B measurements, tests) */
+#define ARX_TOPK_NO_SINGLE_ROW_TAIL 8 /* flags: take the select + rescore kernel pair (all 64 rows of each selected group) where the library would take the
+                                      single-kernel tail that rescoring only the arg-max 4-row block (fp16 pass: batches of <= 256 queries, k <= 10, shards
+                                      of <= 1 M rows) or the arg-max row (int8 pipeline's first step) of each selected group — A/B measurements, tests */
 #define ARX_TOPK_SCAN_ONLY     2   /* flags: run only pass A (the scan of the shard: every CU, HBM-bound) and leave its result in the workspace */
 #define ARX_TOPK_TAIL_ONLY     4   /* flags: run only what follows pass A (select, exact rescoring, certificate) on a workspace a SCAN_ONLY call
                                       with the same arguments filled; the caller orders the two calls (possibly on two streams with different
