@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Dev: where does the aux epilogue's 4 % of pass A go?  pass-A time (library events) on the 625 k x 768 shard at 64 / 256 queries per build:
 the shipped library, ARX_AUXDBG=1 (aux computed, NOT stored), ARX_AUXDBG=2 (no keyed maxima, a constant stored), and the shipped library with
-the pair path (no aux at all); builds alternate in child processes."""
+the pair path (no aux at all); builds alternate in child processes.
+(The two timing builds were one-off edits of groupmax_epilogue_f16_aux behind -DARX_AUXDBG — skip the second store_query_row / replace the keyed
+maxima by a constant — and are not in the tree; result: profiles/r04/aux_epilogue_cost_probe.txt.)"""
 import json, os, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
