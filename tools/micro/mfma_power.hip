@@ -63,6 +63,52 @@ __global__ __launch_bounds__(512) void spin(const bf16x8* __restrict__ src, floa
     if (keep == 12345.678f) out[0] = keep;
 }
 
+// mode 2: the 16x16x32 loop with its 12 fragments RE-READ from LDS every iteration (12 ds_read_b128 per 32 MFMAs: the GEMM's ratio, 24 reads per
+//         64-deep k-tile of a 128 x 64 wave tile); LDS filled once with the random operands
+// mode 3: mode 2 + the operand stream: 4 x 1-KB LDS-DMA pieces per wave and iteration from an L2-resident 8-MB buffer (a 256 x 256 block tile
+//         stages 64 KB per k-tile = 8 KB per wave per 64 MFMAs), behind a counted vmcnt
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) void gbl_void_t;
+template <int MODE>
+__global__ __launch_bounds__(512) void spin_lds(const bf16x8* __restrict__ src, const char* __restrict__ stream, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    bf16x8* frag = reinterpret_cast<bf16x8*>(smem);                 // [12][512] fragments: one 16-B slot per thread and fragment index
+    for (int i = 0; i < 12; ++i) frag[i * 512 + threadIdx.x] = src[(i * 64 + lane + threadIdx.x) & 4095];
+    __syncthreads();
+    char* dma = smem + 12 * 512 * 16 + wid * 4096;                  // 4 KB per wave of DMA landing zone
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t gbase = ((size_t)(blockIdx.x * 8 + wid) * 4096) % (8u << 20);        // this wave's 1-KB pieces start here (8-MB ring + 1 MB of slack)
+    for (int it = 0; it < iters; ++it) {
+        bf16x8 a[8], b[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = frag[i * 512 + ((threadIdx.x + it) & 511)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = frag[(8 + i) * 512 + ((threadIdx.x + it) & 511)];
+        if constexpr (MODE == 3) {
+#pragma unroll
+            for (int pce = 0; pce < 4; ++pce)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(stream + (gbase + (size_t)(it * 4 + pce) * 65536) % (8u << 20) + lane * 16),
+                                                 (lds_void_t*)(dma + pce * 1024), 16, 0, 0);       // < 8 MB + 1 KB: inside the 9-MB allocation
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
+        if constexpr (MODE == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    float keep = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) keep += acc[j][i][0] + acc[j][i][3];
+    if (keep == 12345.678f) out[0] = keep + dma[0];
+}
+
 int main(int argc, char** argv) {
     const int mode = argc > 1 ? atoi(argv[1]) : 0;
     const double secs = argc > 2 ? atof(argv[2]) : 3.0;
@@ -79,9 +125,27 @@ int main(int argc, char** argv) {
     int cus = 0; hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     const int iters = 20000;                                  // 32 (or 16) MFMAs per iteration
     const double flop_per_launch = (double)cus * 8 /*waves*/ * iters * 2.0 * 128 * 64 * 32;
+    char* stream = nullptr;
+    hipMalloc(&stream, (8u << 20) + (1u << 20));
+    hipMemset(stream, 0x3c, (8u << 20) + (1u << 20));
+    {                                                          // random bytes in the stream too
+        unsigned* hs = (unsigned*)malloc(8u << 20);
+        for (size_t i = 0; i < (8u << 20) / 4; ++i) hs[i] = (unsigned)rand() * 2654435761u;
+        hipMemcpy(stream, hs, 8u << 20, hipMemcpyHostToDevice);
+        if (zero) hipMemset(stream, 0, 8u << 20);
+        free(hs);
+    }
+    const int smem_bytes = 12 * 512 * 16 + 8 * 4096;
     auto launch = [&]() {
-        if (mode == 0) spin<0><<<cus, 512>>>(src, out, iters); else spin<1><<<cus, 512>>>(src, out, iters);
+        if (mode == 0) spin<0><<<cus, 512>>>(src, out, iters);
+        else if (mode == 1) spin<1><<<cus, 512>>>(src, out, iters);
+        else if (mode == 2) spin_lds<2><<<cus, 512, smem_bytes>>>(src, stream, out, iters);
+        else spin_lds<3><<<cus, 512, smem_bytes>>>(src, stream, out, iters);
     };
+    if (mode >= 2) {
+        hipFuncSetAttribute((const void*)spin_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+        hipFuncSetAttribute((const void*)spin_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+    }
     launch(); hipDeviceSynchronize();
     auto t0 = std::chrono::steady_clock::now();
     int n = 0;
@@ -93,6 +157,7 @@ int main(int argc, char** argv) {
         el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     printf("{\"mode\": \"%s\", \"zero_operands\": %d, \"launches\": %d, \"seconds\": %.3f, \"tflops\": %.1f}\n",
-           mode == 0 ? "16x16x32" : "32x32x16", zero, n, el, flop_per_launch * n / el / 1e12);
+           mode == 0 ? "16x16x32" : mode == 1 ? "32x32x16" : mode == 2 ? "16x16x32 + LDS fragment reads" : "16x16x32 + LDS reads + L2->LDS DMA stream", zero, n, el,
+           flop_per_launch * n / el / 1e12);
     return 0;
 }

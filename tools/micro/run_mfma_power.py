@@ -21,7 +21,7 @@ def sample(stop, out):
         stop.wait(0.25)
 
 
-for mode in (0, 1, 0, 1):
+for mode in ([int(a) for a in sys.argv[1:]] or (0, 2, 3, 1, 0, 2, 3)):
     for zero in (0, 1):
         stop, samples = threading.Event(), []
         th = threading.Thread(target=sample, args=(stop, samples)); th.start()
