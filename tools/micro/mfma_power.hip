@@ -109,6 +109,49 @@ __global__ __launch_bounds__(512) void spin_lds(const bf16x8* __restrict__ src, 
     if (keep == 12345.678f) out[0] = keep + dma[0];
 }
 
+// mode 4 / 5: the OTHER geometry — ONE wave per SIMD with a 128 x 128 wave tile (64 accumulator blocks = 256 accumulator registers; 256-thread
+// blocks, one per CU): 16 fragment reads per 64 MFMAs (a third of mode 2's reads per FLOP); mode 5 adds the operand stream (a 256 x 256 block
+// tile still stages 64 KB per k-tile: 16 KB = 16 pieces per wave per 128 MFMAs, i.e. 8 per iteration of 64)
+template <int MODE>
+__global__ __launch_bounds__(256) void spin_big(const bf16x8* __restrict__ src, const char* __restrict__ stream, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    bf16x8* frag = reinterpret_cast<bf16x8*>(smem);                 // [16][256]
+    for (int i = 0; i < 16; ++i) frag[i * 256 + threadIdx.x] = src[(i * 64 + lane + threadIdx.x) & 4095];
+    __syncthreads();
+    char* dma = smem + 16 * 256 * 16 + wid * 8192;
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t gbase = ((size_t)(blockIdx.x * 4 + wid) * 8192) % (8u << 20);
+    for (int it = 0; it < iters; ++it) {
+        bf16x8 a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = frag[i * 256 + ((threadIdx.x + it) & 255)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = frag[(8 + i) * 256 + ((threadIdx.x + it) & 255)];
+        if constexpr (MODE == 5) {
+#pragma unroll
+            for (int pce = 0; pce < 8; ++pce)
+                __builtin_amdgcn_global_load_lds((gbl_void_t*)(stream + (gbase + (size_t)(it * 8 + pce) * 65536) % (8u << 20) + lane * 16),
+                                                 (lds_void_t*)(dma + pce * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
+        if constexpr (MODE == 5) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    }
+    float keep = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) keep += acc[j][i][0] + acc[j][i][3];
+    if (keep == 12345.678f) out[0] = keep + dma[0];
+}
+
 int main(int argc, char** argv) {
     const int mode = argc > 1 ? atoi(argv[1]) : 0;
     const double secs = argc > 2 ? atof(argv[2]) : 3.0;
@@ -124,7 +167,8 @@ int main(int argc, char** argv) {
     hipMemcpy(src, h, 4096 * 16, hipMemcpyHostToDevice);
     int cus = 0; hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     const int iters = 20000;                                  // 32 (or 16) MFMAs per iteration
-    const double flop_per_launch = (double)cus * 8 /*waves*/ * iters * 2.0 * 128 * 64 * 32;
+    const double flop_per_launch = mode >= 4 ? (double)cus * 4 /*waves*/ * iters * 2.0 * 128 * 128 * 32
+                                             : (double)cus * 8 /*waves*/ * iters * 2.0 * 128 * 64 * 32;
     char* stream = nullptr;
     hipMalloc(&stream, (8u << 20) + (1u << 20));
     hipMemset(stream, 0x3c, (8u << 20) + (1u << 20));
@@ -136,12 +180,17 @@ int main(int argc, char** argv) {
         free(hs);
     }
     const int smem_bytes = 12 * 512 * 16 + 8 * 4096;
+    const int smem_big = 16 * 256 * 16 + 4 * 8192;
     auto launch = [&]() {
         if (mode == 0) spin<0><<<cus, 512>>>(src, out, iters);
         else if (mode == 1) spin<1><<<cus, 512>>>(src, out, iters);
         else if (mode == 2) spin_lds<2><<<cus, 512, smem_bytes>>>(src, stream, out, iters);
-        else spin_lds<3><<<cus, 512, smem_bytes>>>(src, stream, out, iters);
+        else if (mode == 3) spin_lds<3><<<cus, 512, smem_bytes>>>(src, stream, out, iters);
+        else if (mode == 4) spin_big<4><<<cus, 256, smem_big>>>(src, stream, out, iters);
+        else spin_big<5><<<cus, 256, smem_big>>>(src, stream, out, iters);
     };
+    hipFuncSetAttribute((const void*)spin_big<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_big);
+    hipFuncSetAttribute((const void*)spin_big<5>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_big);
     if (mode >= 2) {
         hipFuncSetAttribute((const void*)spin_lds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
         hipFuncSetAttribute((const void*)spin_lds<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
@@ -157,7 +206,8 @@ int main(int argc, char** argv) {
         el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     printf("{\"mode\": \"%s\", \"zero_operands\": %d, \"launches\": %d, \"seconds\": %.3f, \"tflops\": %.1f}\n",
-           mode == 0 ? "16x16x32" : mode == 1 ? "32x32x16" : mode == 2 ? "16x16x32 + LDS fragment reads" : "16x16x32 + LDS reads + L2->LDS DMA stream", zero, n, el,
+           mode == 0 ? "16x16x32" : mode == 1 ? "32x32x16" : mode == 2 ? "16x16x32 + LDS fragment reads" : mode == 3 ? "16x16x32 + LDS reads + L2->LDS DMA stream" :
+           mode == 4 ? "128x128 wave tile, 1 wave/SIMD: 16x16x32 + LDS fragment reads" : "128x128 wave tile, 1 wave/SIMD: + L2->LDS DMA stream", zero, n, el,
            flop_per_launch * n / el / 1e12);
     return 0;
 }
