@@ -66,7 +66,7 @@ class ShardIndex:
         """Upper bound on the L2 norm of the shard's rows (measured on the device unless the caller gave one)."""
         if self._norm_given is not None:
             return self._norm_given
-        if self._norm is None or self._norm_version != self.corpus._version:
+        if self._norm is None or self._norm_version != self.corpus._version or self._norm_version < 0:
             out = torch.empty(1, dtype=torch.float32, device=self.corpus.device)
             _lib.check(self.lib.arx_rows_max_norm_f16(self.corpus.data_ptr(), self.n_rows, self.dim, out.data_ptr(),
                                                       torch.cuda.current_stream().cuda_stream), "arx_rows_max_norm_f16")
@@ -85,6 +85,14 @@ class ShardIndex:
         self.max_row_norm()
         if self._i8 is not None and not self.prefilter_disabled and self.corpus._version != self._i8_version:
             self.build_int8()
+
+    def invalidate(self):
+        """Tell the index its rows were written BEHIND torch's back (through a raw pointer: the encoder kernels filling a slice of the shard
+        via `device_f16_out`, another library): the tensor's version counter does not see such writes, so the int8 copy and the norm
+        bound would silently describe rows that no longer exist.  The next search re-derives both.  (Writes through torch ops are noticed
+        without this.)"""
+        self._norm_version = -1
+        self._i8_version = -1
 
     def _use_i8(self) -> bool:
         return self._i8 is not None and not self.prefilter_disabled and self.i8_max_queries != 0

@@ -459,6 +459,19 @@ def test_search_rows_of_any_norm_stay_exact(hip):
     # rows written later are seen (the bound follows the tensor's version counter, like the int8 copy)
     ct[9] = ct[9] * 0 + 30.0
     assert idx.max_row_norm() >= 30.0 * np.sqrt(d) * 0.999
+    # ... and rows written through a raw pointer (the encoder kernels, another library) after `invalidate()`
+    from arxiv_rag_amd.index import fill_unit_rows
+    lib = hip.load()
+    hip.check(lib.arx_fill_unit_rows_f16_at(ct.data_ptr(), 128, d, 5, 0, torch.cuda.current_stream().cuda_stream), "fill")     # rows 0..127 unit again
+    ct8 = ct.clone(); i9 = ShardIndex(ct8, prefilter="int8")
+    assert i9.max_row_norm() > 8.0                                             # (measured and cached now)
+    hip.check(lib.arx_fill_unit_rows_f16_at(ct8.data_ptr(), ct8.shape[0], d, 6, 0, torch.cuda.current_stream().cuda_stream), "fill")
+    assert i9.max_row_norm() > 8.0                                             # stale: torch did not see the write
+    i9.invalidate()
+    assert i9.max_row_norm() < 1.01
+    qn = fill_unit_rows(6, d, seed=77)
+    s9, id9 = i9.search(qn, 10)
+    _assert_topk_valid(ct8.cpu().numpy(), qn.cpu().numpy(), s9.cpu().numpy(), id9.cpu().numpy(), 10, tol=2e-6)
 
 
 def test_two_indices_with_their_own_policies_from_two_host_threads(hip):
