@@ -109,6 +109,51 @@ __global__ __launch_bounds__(512) void spin_lds(const bf16x8* __restrict__ src, 
     if (keep == 12345.678f) out[0] = keep + dma[0];
 }
 
+// mode 6: mode 3 with the B fragments NOT through LDS: each lane loads its 4 B fragments (16 B each) straight from the L2-resident ring
+//         (W is an L2-resident operand in the encoder), A fragments from LDS (8 reads), the DMA stream carries the A half only (2 pieces)
+__global__ __launch_bounds__(512) void spin_bdirect(const bf16x8* __restrict__ src, const char* __restrict__ stream, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    bf16x8* frag = reinterpret_cast<bf16x8*>(smem);
+    for (int i = 0; i < 8; ++i) frag[i * 512 + threadIdx.x] = src[(i * 64 + lane + threadIdx.x) & 4095];
+    __syncthreads();
+    char* dma = smem + 12 * 512 * 16 + wid * 4096;
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t gbase = ((size_t)(blockIdx.x * 8 + wid) * 4096) % (8u << 20);
+    const size_t bbase = ((size_t)(wid & 3) * 65536 + lane * 16);            // waves of one wave column read the same B lines
+    bf16x8 b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const bf16x8*>(stream + (bbase + i * 1024) % (8u << 20));
+    for (int it = 0; it < iters; ++it) {
+        bf16x8 a[8], bn[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = frag[i * 512 + ((threadIdx.x + it) & 511)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)                                           // next iteration's B fragments, in flight under this iteration's MFMAs
+            bn[i] = *reinterpret_cast<const bf16x8*>(stream + (bbase + (size_t)(it + 1) * 4096 + i * 1024) % (8u << 20));
+#pragma unroll
+        for (int pce = 0; pce < 2; ++pce)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(stream + (gbase + (size_t)(it * 2 + pce) * 65536) % (8u << 20) + lane * 16),
+                                             (lds_void_t*)(dma + pce * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[j][i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[i] = bn[i];
+    }
+    float keep = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) keep += acc[j][i][0] + acc[j][i][3];
+    if (keep == 12345.678f) out[0] = keep + dma[0];
+}
+
 // mode 4 / 5: the OTHER geometry — ONE wave per SIMD with a 128 x 128 wave tile (64 accumulator blocks = 256 accumulator registers; 256-thread
 // blocks, one per CU): 16 fragment reads per 64 MFMAs (a third of mode 2's reads per FLOP); mode 5 adds the operand stream (a 256 x 256 block
 // tile still stages 64 KB per k-tile: 16 KB = 16 pieces per wave per 128 MFMAs, i.e. 8 per iteration of 64)
@@ -167,7 +212,7 @@ int main(int argc, char** argv) {
     hipMemcpy(src, h, 4096 * 16, hipMemcpyHostToDevice);
     int cus = 0; hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     const int iters = 20000;                                  // 32 (or 16) MFMAs per iteration
-    const double flop_per_launch = mode >= 4 ? (double)cus * 4 /*waves*/ * iters * 2.0 * 128 * 128 * 32
+    const double flop_per_launch = (mode == 4 || mode == 5) ? (double)cus * 4 /*waves*/ * iters * 2.0 * 128 * 128 * 32
                                              : (double)cus * 8 /*waves*/ * iters * 2.0 * 128 * 64 * 32;
     char* stream = nullptr;
     hipMalloc(&stream, (8u << 20) + (1u << 20));
@@ -186,9 +231,11 @@ int main(int argc, char** argv) {
         else if (mode == 1) spin<1><<<cus, 512>>>(src, out, iters);
         else if (mode == 2) spin_lds<2><<<cus, 512, smem_bytes>>>(src, stream, out, iters);
         else if (mode == 3) spin_lds<3><<<cus, 512, smem_bytes>>>(src, stream, out, iters);
+        else if (mode == 6) spin_bdirect<<<cus, 512, smem_bytes>>>(src, stream, out, iters);
         else if (mode == 4) spin_big<4><<<cus, 256, smem_big>>>(src, stream, out, iters);
         else spin_big<5><<<cus, 256, smem_big>>>(src, stream, out, iters);
     };
+    hipFuncSetAttribute((const void*)spin_bdirect, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
     hipFuncSetAttribute((const void*)spin_big<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_big);
     hipFuncSetAttribute((const void*)spin_big<5>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_big);
     if (mode >= 2) {
@@ -207,7 +254,8 @@ int main(int argc, char** argv) {
     }
     printf("{\"mode\": \"%s\", \"zero_operands\": %d, \"launches\": %d, \"seconds\": %.3f, \"tflops\": %.1f}\n",
            mode == 0 ? "16x16x32" : mode == 1 ? "32x32x16" : mode == 2 ? "16x16x32 + LDS fragment reads" : mode == 3 ? "16x16x32 + LDS reads + L2->LDS DMA stream" :
-           mode == 4 ? "128x128 wave tile, 1 wave/SIMD: 16x16x32 + LDS fragment reads" : "128x128 wave tile, 1 wave/SIMD: + L2->LDS DMA stream", zero, n, el,
+           mode == 4 ? "128x128 wave tile, 1 wave/SIMD: 16x16x32 + LDS fragment reads" : mode == 5 ? "128x128 wave tile, 1 wave/SIMD: + L2->LDS DMA stream" :
+           "16x16x32: A fragments from LDS, B fragments straight from L2, A-only DMA stream", zero, n, el,
            flop_per_launch * n / el / 1e12);
     return 0;
 }
