@@ -25,6 +25,7 @@
 #define QBATCH_MAX 1024              // queries per internal pass (bounds the gmax workspace)
 #define AUX16_MAX_NQ 256              // fp16 pass: query batches up to this size (one 256-query tile) write aux words and take the single-row tail
 #define TAIL_INBLOCK_MAX_SUPER 1024   // ... on shards of up to this many super-groups (1 M rows): there the block also selects for itself
+#define SURV_CAP 256                 // int8 pipeline: rows at or above the threshold kept per query
 #define CNT_QCOUNT 2                 // layout of the int8 candidate pipeline's counter block: see collect_pairs_kernel
 #define CNT_QOVER (2 + QBATCH_MAX)
 #define CNT_INTS (2 + 2 * QBATCH_MAX)
@@ -290,7 +291,9 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
 // unit rows the slack is ~0.026, so ~150 groups per query reach the threshold; the candidate pipeline below (collect_pairs_kernel ->
 // pair_rescore_kernel -> merge_survivors_kernel) rescoring ONE row of almost every such group (aux word) settles them.
 __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __restrict__ X, int64_t n_rows, int D, int8_t* __restrict__ X8,
-                                                                float2* __restrict__ meta) {
+                                                                float2* __restrict__ meta, unsigned long long* __restrict__ zero_stats) {
+    // (quantising a QUERY batch is the first kernel of an int8 search: the call's certificate counters start at zero here)
+    if (zero_stats && blockIdx.x == 0 && threadIdx.x < 2) zero_stats[threadIdx.x] = 0ull;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n_rows) return;
@@ -860,7 +863,10 @@ __global__ __launch_bounds__(NT) void rescore_kernel(const float* __restrict__ p
 //   (4) top-k of the candidates; (5) certificate exactly as rescore_kernel's: U bounds every row in a group that was not selected; rows of a
 //       selected, unexpanded group other than its arg-max row have pass-A score <= ub2 < thr' <= thr (s_k only grows as rows are added),
 //       so they are covered too.  The fallback (every unscored group with gmax >= thr) is the same code.
-template <int K, int NT, int RS, bool INBLOCK, bool COLLECT, int CW>
+#define I8D_CAP_ROWS 2048            // single-kernel int8 tail: (query, row) candidates a block lists before it gives up and scans exhaustively
+#define I8D_CAP_GROUPS 512           // ... (query, group) candidates
+#define I8D_EXTRA_SMEM (I8D_CAP_ROWS * 4 + I8D_CAP_GROUPS * 4 + SURV_CAP * 12)
+template <int K, int NT, int RS, bool INBLOCK, bool COLLECT, int CW, bool I8D = false>
 __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict__ gmax, const uint32_t* __restrict__ aux, int64_t ldg,
                                                           int64_t n_groups, const float* __restrict__ part_s, const int32_t* __restrict__ part_g,
                                                           int nslices, const f16_t* __restrict__ Q, const f16_t* __restrict__ C,
@@ -1048,7 +1054,7 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
                 out_i[(int64_t)q * k + better] = mi + idx_base;
             }
             if (lane >= nvalid && lane < k) { out_s[(int64_t)q * k + lane] = -INFINITY; out_i[(int64_t)q * k + lane] = -1; }
-            const bool flag = !COLLECT && sh_u > -INFINITY && sh_u >= thr0;
+            const bool flag = !COLLECT && !I8D && sh_u > -INFINITY && sh_u >= thr0;
             if (lane == 0) { sh_flag = flag ? 1 : 0; sh_thr = thr0; }
             if constexpr (COLLECT) {
                 if (lane == 0) {
@@ -1058,7 +1064,7 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
                 }
                 if (lane < K) selg_out[q * K + lane] = sel_g[lane];
             }
-            if (flag) {                                          // the fallback starts from the sorted list in gs / gi_[0..k)
+            if (flag || I8D) {                                   // the fallback / the candidate pass start from the sorted list in gs / gi_[0..k)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane < NC) { gs[cg * GROUP_ROWS + lane % CW] = -INFINITY; gi_[cg * GROUP_ROWS + lane % CW] = -1; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1103,7 +1109,7 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const bool full = gi_[k - 1] >= 0;
             const float thr = full ? gs[k - 1] - tau_scale * sh_qn : -INFINITY;
-            const bool flag = !COLLECT && sh_u > -INFINITY && sh_u >= thr;
+            const bool flag = !COLLECT && !I8D && sh_u > -INFINITY && sh_u >= thr;
             if (lane == 0) { sh_flag = flag ? 1 : 0; sh_thr = thr; }
             if (!flag && lane < k) {
                 out_s[(int64_t)q * k + lane] = gs[lane];
@@ -1120,7 +1126,91 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
         }
         __syncthreads();
     }
-    if (COLLECT || !sh_flag) return;                            // block-uniform
+    if constexpr (I8D) {
+        // ---- int8 pass, small shard: the candidate step INSIDE this block (round 4: one launch instead of collect_pairs -> pair_rescore ->
+        // merge_survivors -> redo, whose four dependent launches were 0.08 ms of a 0.25-ms batch on the 625 k-row slice).  The block reads
+        // its query's column of UPPER BOUNDS once more (L2 hits); every group at or above the threshold that is not one of the K selected
+        // ones becomes a (row) candidate when its second bound is below the threshold, a (group) candidate otherwise; the block's 16
+        // waves rescoring them (8 lanes per row: 128 rows per step), rows at or above the threshold survive and are merged with the
+        // provisional top-k.  More candidates than the lists hold (adversarial data) -> the exhaustive fallback below, which is exact.
+        uint32_t* lrow = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(gi_) + K * GROUP_ROWS * 8);
+        uint32_t* lgrp = lrow + I8D_CAP_ROWS;
+        float* sv_s = reinterpret_cast<float*>(lgrp + I8D_CAP_GROUPS);
+        int64_t* sv_i = reinterpret_cast<int64_t*>(sv_s + SURV_CAP);
+        __shared__ int n_r, n_g, n_s, ovf;
+        if (tid == 0) { n_r = 0; n_g = 0; n_s = 0; ovf = 0; }
+        __syncthreads();
+        const float thr = sh_thr;
+        for (int64_t g = tid; g < n_groups; g += NT) {
+            const float v = gmax[g * ldg + q];
+            if (!(v >= thr)) continue;
+            bool sel = false;
+#pragma unroll 4
+            for (int jj = 0; jj < K; ++jj) sel = sel || (sel_g[jj] == (int32_t)g);
+            if (sel) continue;
+            const uint32_t a = aux[g * ldg + q];
+            const int64_t row = g * GROUP_ROWS + (int64_t)(a & 63u);
+            if (__uint_as_float(a & 0xFFFF0000u) < thr && row < n_rows) {
+                const int sl = atomicAdd(&n_r, 1);
+                if (sl < I8D_CAP_ROWS) lrow[sl] = (uint32_t)row; else ovf = 1;
+            } else {
+                const int sl = atomicAdd(&n_g, 1);
+                if (sl < I8D_CAP_GROUPS) lgrp[sl] = (uint32_t)g; else ovf = 1;
+            }
+        }
+        __syncthreads();
+        if (!ovf) {                                               // block-uniform
+            const int nr = n_r, ng = n_g;
+            for (int base = w * 8; base < nr; base += NW * 8) {
+                const int p0 = base + rsub;
+                const bool ok = p0 < nr;
+                const int64_t row = (int64_t)lrow[ok ? p0 : 0];
+                const float a = exact_row_score(C + row * D, qs, nch, l8, ok);
+                if (l8 == 0 && ok && a >= thr) {
+                    const int sl = atomicAdd(&n_s, 1);
+                    if (sl < SURV_CAP) { sv_s[sl] = a; sv_i[sl] = row; } else ovf = 1;
+                }
+            }
+            for (int p0 = w; p0 < ng; p0 += NW) {
+                const int64_t gg = (int64_t)lgrp[p0];
+                for (int r8 = 0; r8 < GROUP_ROWS; r8 += 8) {
+                    const int64_t row = gg * GROUP_ROWS + r8 + rsub;
+                    const bool ok = row < n_rows;
+                    const float a = exact_row_score(C + (ok ? row : 0) * D, qs, nch, l8, ok);
+                    if (l8 == 0 && ok && a >= thr) {
+                        const int sl = atomicAdd(&n_s, 1);
+                        if (sl < SURV_CAP) { sv_s[sl] = a; sv_i[sl] = row; } else ovf = 1;
+                    }
+                }
+            }
+            __syncthreads();
+            if (!ovf) {                                           // block-uniform
+                if (w == 0) {
+                    const int ns = n_s;
+                    constexpr int R = SURV_CAP / 64 + 1;
+                    float s[R]; int64_t id[R];
+#pragma unroll
+                    for (int j = 0; j < R - 1; ++j) {
+                        const int i = j * 64 + lane;
+                        s[j] = i < ns ? sv_s[i] : -INFINITY;
+                        id[j] = i < ns ? sv_i[i] : -1;
+                    }
+                    s[R - 1] = lane < k ? gs[lane] : -INFINITY;
+                    id[R - 1] = lane < k ? gi_[lane] : -1;
+                    wave_topk<R>(s, id, k, lane, w_s[0], w_i[0]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane < k) {
+                        out_s[(int64_t)q * k + lane] = w_s[0][lane];
+                        out_i[(int64_t)q * k + lane] = w_i[0][lane] >= 0 ? w_i[0][lane] + idx_base : -1;
+                    }
+                    if (stats && lane == 0) atomicAdd(&stats[1], (unsigned long long)(nr + ng));
+                }
+                return;
+            }
+        }
+        // too many candidates or survivors for the lists: answered exhaustively below (counted as a slow-path query)
+    }
+    if (COLLECT || (!I8D && !sh_flag)) return;                  // block-uniform
 
     // ---- certificate fallback (as rescore_kernel's): every group whose pass-A maximum reaches the threshold and that is not among the K
     // selected ones is rescored in full.  A selected group that was NOT expanded is skipped with them: its rows other than the arg-max
@@ -1185,7 +1275,6 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
 
 // ---- int8 pre-filter: the candidates beyond the K selected groups, in three coalesced / parallel steps ---------------------------------
 #define PAIR_CAP_PER_QUERY 4096      // (query, group) pairs kept per query; a query that needs more is re-run ALONE by the exhaustive kernel
-#define SURV_CAP 256                 // rows at or above the threshold kept per query
 // counters (ints): [0] (query, group) pairs appended, [1] (query, row) pairs appended, [2, 2 + QBATCH_MAX) pairs seen per query, [2 + QBATCH_MAX, 2 + 2 QBATCH_MAX)
 // per-query overflow flag.  Overflow is PER QUERY: every query appends at most PAIR_CAP_PER_QUERY pairs, so the shared list
 // (nq x PAIR_CAP_PER_QUERY slots) cannot overflow, and one clustered query whose bound lets thousands of groups through sends only itself
@@ -1561,7 +1650,7 @@ extern "C" int32_t arx_topk_build_i8(const void* corpus, int64_t n_rows, int32_t
     const int64_t blocks = (n_rows + 3) / 4;
     ARX_REQUIRE(blocks < (1ll << 31), "too many rows for one launch");
     quantize_rows_i8_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)corpus, n_rows, dim, (int8_t*)index_i8,
-                                                                         (float2*)((char*)index_i8 + i8_meta_offset(n_rows, dim)));
+                                                                         (float2*)((char*)index_i8 + i8_meta_offset(n_rows, dim)), nullptr);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -1591,10 +1680,11 @@ static int launch_collect_rescore(const TopkWs& L, char* ws, const float* gmax, 
 }
 
 // The int8 pipeline with ONE row per selected group in its first step (default; aux is written by the int8 pass anyway):
-//   [select_groups, only on shards beyond TAIL_INBLOCK_MAX_SUPER super-groups] -> tail_single_kernel<COLLECT> (provisional top-k, threshold,
-//   selected groups) -> collect_pairs -> pair_rescore (every other (query, group) at or above the threshold: one row of it where the aux
-//   word allows) -> merge_survivors -> tail_single_kernel<only_if> (a query whose own lists overflowed: exhaustive above the threshold).
-// Five launches on a small shard (round 3: six, and 0.47 ms of a 0.63-ms 256-query batch on 625 k rows).
+//   shards of up to TAIL_INBLOCK_MAX_SUPER super-groups (1 M rows), k <= 10: ONE launch, tail_single_kernel<I8D> (round 3: six, and 0.47 ms
+//   of a 0.63-ms 256-query batch on 625 k rows);
+//   larger shards: select_groups -> tail_single_kernel<COLLECT> (provisional top-k, threshold, selected groups) -> collect_pairs ->
+//   pair_rescore (every other (query, group) at or above the threshold: one row of it where the aux word allows) -> merge_survivors ->
+//   tail_single_kernel<only_if> (a query whose own lists overflowed: exhaustive above the threshold).
 template <int K>
 static int run_i8_single(const TopkWs& L, char* ws, const f16_t* Q, int nq, const f16_t* C, int64_t n_rows, int D, int k, float* out_s,
                          int64_t* out_i, int64_t idx_base, float tau_scale, int debug_drop, hipStream_t st, bool first_pass) {
@@ -1625,31 +1715,32 @@ static int run_i8_single(const TopkWs& L, char* ws, const f16_t* Q, int nq, cons
         ARX_HIP_CHECK(hipGetLastError());
     }
     ProfScope psc(ARX_K_SEARCH_RESCORE, st);
-    auto k_in_c = tail_single_kernel<KSEL_SMALL, 1024, 1, true, true, 1>;
-    auto k_in_r = tail_single_kernel<KSEL_SMALL, 1024, 1, true, false, 1>;
     auto k_pl_c = tail_single_kernel<K, 1024, R1, false, true, 1>;
     auto k_pl_r = tail_single_kernel<K, 1024, R1, false, false, 1>;
-    if (smem > 48 * 1024) {
-        ARX_HIP_CHECK(arx_func_smem((const void*)(inblock ? k_in_c : k_pl_c), (int)smem));
-        ARX_HIP_CHECK(arx_func_smem((const void*)(inblock ? k_in_r : k_pl_r), (int)smem));
+    if (smem > 48 * 1024 && !inblock) {
+        ARX_HIP_CHECK(arx_func_smem((const void*)k_pl_c, (int)smem));
+        ARX_HIP_CHECK(arx_func_smem((const void*)k_pl_r, (int)smem));
     }
-    if (inblock)
-        k_in_c<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, nullptr, nullptr, 0, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
-                                       debug_drop, nullptr, thr, selg, counters, nsurv, nullptr, first_pass ? stats : nullptr);
-    else
-        k_pl_c<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, ps, pg, L.nsplit, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
-                                       debug_drop, nullptr, thr, selg, counters, nsurv, nullptr, nullptr);
+    if (inblock) {
+        // small shard: ONE launch — selection, one row per selected group, the candidate pass and the merge inside the query's block
+        // (tail_single_kernel<I8D>); the counters were zeroed by the query batch's quantisation kernel
+        auto kd = tail_single_kernel<KSEL_SMALL, 1024, 1, true, false, 1, true>;
+        const size_t smem_d = smem + I8D_EXTRA_SMEM;
+        if (smem_d > 48 * 1024) ARX_HIP_CHECK(arx_func_smem((const void*)kd, (int)smem_d));
+        kd<<<nq, 1024, smem_d, st>>>(gmax, aux, L.ldg, L.n_groups, nullptr, nullptr, 0, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
+                                     debug_drop, stats, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        ARX_HIP_CHECK(hipGetLastError());
+        return ARX_OK;
+    }
+    k_pl_c<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, ps, pg, L.nsplit, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
+                                   debug_drop, nullptr, thr, selg, counters, nsurv, nullptr, nullptr);
     ARX_HIP_CHECK(hipGetLastError());
     if (int rc = launch_collect_rescore(L, ws, gmax, aux, n_rows, nq, thr, selg, K, Q, C, D, surv_s, surv_i, nsurv, counters, st)) return rc;
     merge_survivors_kernel<<<cdiv(nq, 4), 256, 0, st>>>(out_s, out_i, nq, k, idx_base, surv_s, surv_i, nsurv, counters, redo, stats);
     ARX_HIP_CHECK(hipGetLastError());
     // (merge_survivors already counted the queries that go through this)
-    if (inblock)
-        k_in_r<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, nullptr, nullptr, 0, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
-                                       debug_drop, nullptr, nullptr, nullptr, nullptr, nullptr, redo, nullptr);
-    else
-        k_pl_r<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, ps, pg, L.nsplit, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
-                                       debug_drop, nullptr, nullptr, nullptr, nullptr, nullptr, redo, nullptr);
+    k_pl_r<<<nq, 1024, smem, st>>>(gmax, aux, L.ldg, L.n_groups, ps, pg, L.nsplit, Q, C, n_rows, D, k, out_s, out_i, idx_base, tau_scale,
+                                   debug_drop, nullptr, nullptr, nullptr, nullptr, nullptr, redo, nullptr);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -1800,7 +1891,7 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         } else if (use_i8) {                           // pass A over the int8 representation: upper bounds instead of scores, everything after it unchanged
             int8_t* q8 = (int8_t*)((char*)ws + L.q8);
             float2* qmeta = (float2*)((char*)ws + L.qmeta);
-            quantize_rows_i8_kernel<<<cdiv(nq, 4), 256, 0, st>>>(Q, nq, dim, q8, qmeta);
+            quantize_rows_i8_kernel<<<cdiv(nq, 4), 256, 0, st>>>(Q, nq, dim, q8, qmeta, q0 == 0 ? (unsigned long long*)((char*)ws + L.stats) : nullptr);
             ARX_HIP_CHECK(hipGetLastError());
             const int8_t* C8 = (const int8_t*)index_i8;
             const float2* cmeta = (const float2*)((const char*)index_i8 + i8_meta_offset(n_rows, dim));
