@@ -913,7 +913,24 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
     // 156 k strided loads, takes longer than the select grid it replaces: 0.21 against 0.13 ms per 64-query batch) or taken from the select
     // kernel's partial lists (RS = candidates per lane of up to 256 slices x K entries)
     __shared__ float w_vb[NW];
-    if constexpr (!INBLOCK) {
+    // I8D (int8 pass, small shard): the candidate pass below examines EVERY group at or above the threshold anyway, so the selection only has
+    // to produce a good threshold, not the exact K best groups: each wave contributes the best group of its threads' groups (one wave
+    // all-reduce instead of two 13-round top-k reductions and an expansion), the 12 best of those 16 are the selected groups.  The bounds
+    // a thread read stay in its registers: the candidate pass does not read the column again.
+    constexpr int GPT = I8D ? (TAIL_INBLOCK_MAX_SUPER * SUPER + NT - 1) / NT : 1;      // groups per thread (16 at 1 024 threads)
+    float gv[GPT];
+    if constexpr (I8D) {
+        static_assert(!I8D || (INBLOCK && K <= NW), "one selected group per wave at most");
+        float bs = -INFINITY; int64_t bg = INT64_MAX;
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            const int64_t g = (int64_t)j * NT + tid;
+            gv[j] = g < n_groups ? gmax[g * ldg + q] : -INFINITY;
+            if (g < n_groups && gv[j] > bs) { bs = gv[j]; bg = g; }          // ascending g: ties keep the lower group
+        }
+        wave_argbest(bs, bg);
+        if (lane == 0) { w_s[w][0] = bs; w_i[w][0] = bg == INT64_MAX ? -1 : bg; w_vb[w] = -INFINITY; }
+    } else if constexpr (!INBLOCK) {
         const int ncand = nslices * K;
         float s[RS]; int64_t id[RS];
         float vb = -INFINITY;
@@ -960,6 +977,24 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
     }
     __syncthreads();
     if (w == 0) {
+      float u = -INFINITY;
+      if constexpr (I8D) {
+        // the waves' best groups ranked by (bound desc, group asc) with shuffles; ranks 0 .. K-1 are the selected groups
+        const float my = lane < NW ? w_s[lane][0] : -INFINITY;
+        const int64_t mg = lane < NW ? w_i[lane][0] : -1;
+        int better = 0;
+#pragma unroll 4
+        for (int j = 0; j < NW; ++j) {
+            const float sj = __shfl(my, j);
+            const int64_t gj = __shfl(mg, j);
+            better += (gj >= 0 && mg >= 0 && cand_better(sj, gj, my, mg)) ? 1 : 0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < K1) { w_s[0][lane] = -INFINITY; w_i[0][lane] = -1; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (mg >= 0 && better < K1) { w_s[0][better] = my; w_i[0][better] = mg; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      } else {
         constexpr int R2 = (NW * K1 + 63) / 64;
         float s[R2]; int64_t id[R2];
 #pragma unroll
@@ -970,7 +1005,7 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
         }
         wave_topk<R2>(s, id, K1, lane, gs, gi_);               // K best super-groups -> gs/gi_[0..K), best left out -> [K]
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float u = gi_[K] >= 0 ? gs[K] : -INFINITY;
+        u = gi_[K] >= 0 ? gs[K] : -INFINITY;
 #pragma unroll
         for (int ww = 0; ww < NW; ++ww) u = fmaxf(u, w_vb[ww]);
         // (2) expand to K*SUPER groups, reduce to the K best groups (+ the best one left out)
@@ -992,6 +1027,7 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
         wave_topk<R3>(s3, id3, K1, lane, w_s[0], w_i[0]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (w_i[0][K] >= 0) u = fmaxf(u, w_s[0][K]);
+      }
         if (debug_drop && w_i[0][0] >= 0) u = fmaxf(u, w_s[0][0]);
         if (lane < K) {
             const int32_t g = !debug_drop ? (int32_t)w_i[0][lane] : (lane + 1 < K ? (int32_t)w_i[0][lane + 1] : -1);
@@ -1141,9 +1177,11 @@ __global__ __launch_bounds__(NT) void tail_single_kernel(const float* __restrict
         if (tid == 0) { n_r = 0; n_g = 0; n_s = 0; ovf = 0; }
         __syncthreads();
         const float thr = sh_thr;
-        for (int64_t g = tid; g < n_groups; g += NT) {
-            const float v = gmax[g * ldg + q];
-            if (!(v >= thr)) continue;
+#pragma unroll
+        for (int j = 0; j < GPT; ++j) {
+            const int64_t g = (int64_t)j * NT + tid;
+            const float v = gv[j];                                // the bound this thread read in the selection step
+            if (g >= n_groups || !(v >= thr)) continue;
             bool sel = false;
 #pragma unroll 4
             for (int jj = 0; jj < K; ++jj) sel = sel || (sel_g[jj] == (int32_t)g);
