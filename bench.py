@@ -905,6 +905,18 @@ def main():
                 e["certificate"] = {"queries_on_the_slow_path": fl, "extra_groups_rescored": ex, "of_queries": min(qb, 1024)}
                 res_e[f"Qb={qb}"] = e
             pair_cos = float((e2e_rows[:2048].float() @ e2e_rows[2048:4096].float().T).mean().item())
+            # the int8 first pass on THESE rows (all within cosine ~0.98 of each other: the bound's slack exceeds their spread, every group is a
+            # candidate): what the `adaptive` index (the CLI's and HipCollection's setting) does about it
+            i8_adaptive = None
+            if D_e % 128 == 0 and D_e <= 1024:
+                ia_e = ShardIndex(e2e_rows, idx_base=rank * n_e, prefilter="int8", adaptive=True)
+                torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                s8_, i8_ = ia_e.search(qe[:64], 10)
+                torch.cuda.synchronize(dev); first_ms = (time.perf_counter() - t0) * 1e3
+                s16_, i16_ = ie.search(qe[:64], 10)
+                i8_adaptive = {"prefilter_switched_off_after_first_batch": bool(ia_e.prefilter_disabled), "first_batch_ms": round(first_ms, 3),
+                               "first_batch_rows_identical_to_fp16_pass": bool(torch.equal(i8_, i16_))}
+                del ia_e
             chk = None
             if rank == 0:
                 try:                                                 # exactness vs the oracle (CPU, fp32 on the same fp16 values), 8 queries
@@ -923,7 +935,7 @@ def main():
             e2e = {"workload": f"{n_e} x {D_e} fp16 rows written by the encoder in the sustained leg (rank {rank}'s slice, never left HBM), {nq_e} queries "
                                f"encoded by the same forward ({S} token ids each), top-10 through search_distributed; world {world}",
                    "encode_chunks_per_s": None if sustained is None else sustained["chunks_per_s"], "results": res_e,
-                   "mean_cosine_between_random_rows": round(pair_cos, 4), "vs_oracle": chk}
+                   "mean_cosine_between_random_rows": round(pair_cos, 4), "vs_oracle": chk, "int8_adaptive_index": i8_adaptive}
             del ie, e2e_rows, qe
             torch.cuda.empty_cache()
         except Exception as ex_:                                   # noqa: BLE001
