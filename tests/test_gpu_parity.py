@@ -122,6 +122,34 @@ def test_encoder_vs_oracle_random_batch(hip):
     enc.close()
 
 
+def test_encoder_rows_bitwise_independent_of_random_batch_compositions(hip):
+    """The size-independent property behind the order contract (GEN:146-153 re-batches freely): a row is the same BITS whatever else is in
+    its forward.  A short in-suite cut of tools/encode_soak.py (profiles/r04/encode_soak.txt: 7 765 random compositions of three models,
+    365 M tokens): pool of ragged sequences on tile-edge lengths, random subsets / orders / batch sizes, f32 and fp16 outputs."""
+    from arxiv_rag_amd.encoder import HipEncoder
+    cfg = C.MINILM_L6
+    sd = seeded_state_dict(cfg, seed=21, std=0.04, bias_std=0.02, ln_jitter=0.05)
+    rs = np.random.RandomState(4)
+    edges = [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256]
+    P = 400
+    lens = np.where(rs.rand(P) < 0.4, rs.choice(edges, size=P), rs.randint(1, cfg.max_seq_length + 1, size=P))
+    pool = [rs.randint(4, cfg.vocab_size - 1, size=int(n)).tolist() for n in lens]
+    enc = HipEncoder(cfg, sd)
+    ref16 = torch.zeros((P, cfg.hidden), dtype=torch.float16, device="cuda")
+    ref = enc.encode_ragged(pool, batch_size=256, on_device=True, out_f16=ref16).clone()
+    assert torch.isfinite(ref).all() and (ref.norm(dim=1) - 1).abs().max().item() < 1e-5
+    for trial in range(30):
+        n = int([1, rs.randint(1, 9), rs.randint(9, 120), rs.randint(120, P + 1)][trial % 4])
+        pick = rs.choice(P, size=n, replace=(trial % 5 == 0))
+        bs = int([1, rs.randint(1, 33), rs.randint(33, 257), 1024][(trial // 4) % 4]) if n <= 64 else int(rs.randint(5, 1025))
+        o16 = torch.full((n, cfg.hidden + 8), 7.0, dtype=torch.float16, device="cuda")
+        out = enc.encode_ragged([pool[i] for i in pick], batch_size=bs, on_device=True, out_f16=o16)
+        pk = torch.from_numpy(pick).cuda()
+        assert torch.equal(out, ref[pk]), (trial, n, bs)
+        assert torch.equal(o16[:, :cfg.hidden], ref16[pk]) and (o16[:, cfg.hidden:] == 7.0).all(), (trial, n, bs)
+    enc.close()
+
+
 def test_encoder_empty_rows_and_pad_garbage(hip):
     """len 0 rows give zero vectors; ids beyond lens are ignored whatever they hold (GEN:169 zero-row contract)."""
     from arxiv_rag_amd.encoder import HipEncoder
