@@ -337,6 +337,10 @@ def self_launch(n_gpus: int, argv) -> int:
 
 
 def main():
+    wall, _last = {}, [time.perf_counter()]
+
+    def mark(leg):                                           # where the run's wall time went, leg by leg (printed as `wall_s`)
+        now = time.perf_counter(); wall[leg] = round(wall.get(leg, 0.0) + now - _last[0], 1); _last[0] = now
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -498,6 +502,7 @@ def main():
               "kernels_note": "per-kernel table: separate untimed pass over the same batches with every class recording events; "
                               "roofline.achieved: FFN-1 events inside the timed region"}
 
+    mark("start_up+burst")
     # ---- sustained leg: the whole configs[1] job (1 M chunks = 977 batches, ~50 s) back to back, so that a clock droop under
     # sustained load is visible next to the K-step burst `value` is timed on
     sustained = None
@@ -554,6 +559,7 @@ def main():
         del big
         torch.cuda.empty_cache()
 
+    mark("encode.sustained")
     # ---- search legs ------------------------------------------------------------------------------------
     lib = _lib.load()
 
@@ -677,6 +683,7 @@ def main():
         del corpus, idx
         torch.cuda.empty_cache()
 
+    mark("search.10M")
     # ---- configs[3]: ONE corpus of --search-total-rows rows cut across the ranks (strong scaling), the query set replicated; every rank
     # scans its own slice, one all-gather of the [Q, k] partials over RCCL, merge.  Rank 0 then searches the WHOLE corpus as a single
     # index and checks the merged answer of the first 64 queries against it, bit for bit (the rows are a function of (seed, global row)).
@@ -758,6 +765,7 @@ def main():
         del sidx, shard_rows
         torch.cuda.empty_cache()
 
+    mark("search.strong_scaling+shard_625k")
     # ---- configs[4]'s per-rank slice in the precision that is feasible (fp8 encode: measured infeasible at the 1e-3 bar):
     # a 6.25 M x 1024 fp16 shard (12.8 GB) searched on one GPU
     if args.d1024_rows > 0 and world == 1:
@@ -783,6 +791,7 @@ def main():
         del i4, i48, c4, q4
         torch.cuda.empty_cache()
 
+    mark("search.d1024")
     # ---- search.clustered: the same search on EMBEDDING-LIKE rows (every figure above is on iid Gaussian unit rows, the
     # friendliest case for group-max selection and for the int8 bound).  Clusters of ~500 rows around shared centres + 3 hot dimensions;
     # queries are new points of the same mixture.  Reported: QPS per Qb for the fp16 and int8 first passes, how often the certificate's slow
@@ -879,6 +888,7 @@ def main():
             search["clustered"] = {"error": repr(ex_)[:300]}
             torch.cuda.empty_cache()
 
+    mark("search.clustered")
     # ---- e2e_rank_slice (configs[3]'s real flow, one rank's share): the rows the ENCODER wrote during the sustained leg (the first
     # --e2e-rows of them, still in HBM) are searched where they lie, by queries the encoder also wrote, through search_distributed (RCCL
     # all-gather + merge under a process group).  Seeded-weight embeddings are nearly parallel (every pair of rows has a large cosine):
@@ -942,6 +952,7 @@ def main():
             e2e = {"error": repr(ex_)[:300]}
             torch.cuda.empty_cache()
 
+    mark("e2e_rank_slice")
     # ---- configs[4]'s encode half in the precision that is feasible (fp8: measured infeasible at the 1e-3 bar): bge-large shape
     # (24 L / 1024 / 16 heads / FFN 4096, CLS pool), bf16, 256 chunks x 256 tokens per step
     bge = None
@@ -978,12 +989,14 @@ def main():
         except Exception as ex_:                                   # noqa: BLE001  (an extra leg: its failure must not cost the bench line)
             bge = {"error": repr(ex_)[:300]}
 
+    mark("encode.bge_large")
     encode["sustained"] = sustained
     encode["bge_large"] = bge
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.model, cfg, sd, S, args.cpu_budget)
 
+    mark("cpu_baseline")
     if rank == 0:
         out = {
             "metric": "chunks embedded/sec + QPS@top-10, all-mpnet-base-v2 768-d, 1/2/4/8 MI355X",
@@ -995,6 +1008,7 @@ def main():
                        "global_batch": B * world, "seq_len": S, "parallelism": f"dp{world}",
                        "weights": "seeded N(0,0.02^2), seed 0"},
             "roofline": roofline, "cpu_baseline": cpu, "encode": encode, "search": search, "e2e_rank_slice": e2e, "launch": launch,
+            "wall_s": dict(wall, total=round(sum(wall.values()), 1)),
         }
         print(json.dumps(out))
     if use_dist:
