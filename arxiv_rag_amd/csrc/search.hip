@@ -351,17 +351,22 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
     constexpr int MAIN_BYTES = (BM == 256 && GLDS) ? Gemm8Phase<i8pair_t, 2>::STAGE_OFF : ML::SMEM_BYTES;
     float* const meta = reinterpret_cast<float*>(smem + MAIN_BYTES);          // [512] corpus (s, L1) pairs, then [2 BM] query pairs
     const int lrow = (lane >> 4) * 4;
-    float2 cmr[META_LDS ? 1 : ML::NI][META_LDS ? 1 : 4], qmr[META_LDS ? 1 : ML::MI];
+    // (the 16 corpus pairs a lane's accumulators belong to are the same for the 16 lanes of a row of the wave: lane t of the row loads ONE
+    // pair — row (t>>2)*16 + lrow + (t&3) of the group — and the epilogue fetches the sixteen by ds_bpermute.  Sixteen 8-byte loads per lane
+    // were a third of all the vector-memory requests of a D = 768 tile, half of them at D = 384: 5.8 / 5.0 TB/s where the fp16 pass, the
+    // same bytes per tile at D = 384, reaches 6.3; after: 6.0-6.15 / 5.3-5.5, and 5.5 from 5.25 at 64 queries.  A STREAMED form of this kernel —
+    // a block walking four corpus tiles with its loads running through the tile boundaries and the epilogue under the next tile's first
+    // k-tile — was built beside it and measured: +0-2 % at D = 768, +6-9 % at D = 384, -2 % for the fp16 rows; not kept.
+    // profiles/r04/pass_a_narrow_int8_ab.md)
+    float2 cmr = float2{0.f, 0.f}, qmr[META_LDS ? 1 : ML::MI];
     if constexpr (META_LDS) {
         stage_i8_meta<BM>(cmeta, qmeta, n0, n_rows, m0, nq, meta, threadIdx.x);
     } else {
-#pragma unroll
-        for (int j = 0; j < ML::NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int64_t n = n0 + wn * GROUP_ROWS + j * 16 + lrow + r;
-                cmr[j][r] = cmeta[n < n_rows ? n : n_rows - 1];
-            }
+        {
+            const int t = lane & 15;
+            const int64_t n = n0 + wn * GROUP_ROWS + (t >> 2) * 16 + lrow + (t & 3);
+            cmr = cmeta[n < n_rows ? n : n_rows - 1];
+        }
 #pragma unroll
         for (int i = 0; i < ML::MI; ++i) {
             const int m = m0 + wm * ML::TM + i * 16 + (lane & 15);
@@ -387,7 +392,10 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
     } else {
         groupmax_epilogue_i8<ML::MI, ML::NI>(acc, [&](int j, float2 (&c4)[4]) {
 #pragma unroll
-                                                 for (int r = 0; r < 4; ++r) c4[r] = cmr[j][r];
+                                                 for (int r = 0; r < 4; ++r) {
+                                                     const int src = (lane & 48) | (j * 4 + r);
+                                                     c4[r] = float2{__shfl(cmr.x, src), __shfl(cmr.y, src)};
+                                                 }
                                              },
                                              [&](int i) { return qmr[i]; }, D, gmax + g * ldg, aux + g * ldg, m0 + wm * ML::TM, nq, lane);
     }
