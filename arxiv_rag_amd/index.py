@@ -171,7 +171,7 @@ class ShardIndex:
 
     def certificate_stats(self, ws: Optional[torch.Tensor] = None) -> Tuple[int, int]:
         """(queries whose first selection could not be certified, extra 64-row groups rescored for them) of the LAST `search`
-        on this index (or on `ws`): the answer is exact either way (csrc/search.hip, rescore_kernel step 5); the counters say how often
+        on this index (or on `ws`): the answer is exact either way (csrc/search_tail.h, rescore_kernel step 5); the counters say how often
         the slow path ran.  Where the int8 pre-filter ran the pair is (queries whose OWN candidate lists overflowed and went to the
         exhaustive kernel, (query, group) candidates the pre-filter's bounds let through) instead.
         Synchronises on the current stream."""

@@ -156,7 +156,7 @@ int32_t arx_topk_search(const void* corpus, int64_t n_rows, const void* queries,
  * representation of the shard (row-wise scale + int8 values + the row's L1 norm: dim + 8 bytes per row, caller-owned device buffer of
  * arx_topk_i8_index_bytes(...) bytes); arx_topk_search_i8 then runs its first pass over THAT — half the bytes where the pass is
  * HBM-bound, twice the MFMA rate where it is matrix-bound — computing for every (query, 64-row group) a rigorous UPPER BOUND on the
- * true fp16 score of the group's rows (quantisation error bounded analytically, csrc/search.hip).  Selection, the fp32 rescoring
+ * true fp16 score of the group's rows (quantisation error bounded analytically, csrc/search_pass_a.h).  Selection, the fp32 rescoring
  * of the fp16 rows and the exactness certificate are those of arx_topk_search, so out_scores / out_ids are the same exact top-k
  * (the certificate's exhaustive-by-threshold step absorbs the bound's slack: a few hundred 64-row groups per query on unit rows).
  * dim % 128 == 0, dim <= 1024.  `corpus` is still needed (the rescoring reads it).  The int8 pass needs the LARGER workspace of
@@ -204,7 +204,7 @@ int32_t arx_topk_search_opt(const void* corpus, const void* index_i8, int64_t n_
  * from a user's .npy).  A non-finite row gives +inf/NaN: refuse to index such a shard. */
 int32_t arx_rows_max_norm_f16(const void* rows, int64_t n_rows, int32_t dim, float* out_max, void* stream);
 
-/* Exactness certificate of the LAST arx_topk_search on this workspace (csrc/search.hip, rescore_kernel step 5): the number of
+/* Exactness certificate of the LAST arx_topk_search on this workspace (csrc/search_tail.h, rescore_kernel step 5): the number of
  * queries whose first selection could not be certified (an unscored 64-row group reached the k-th exact score minus the
  * rounding tolerance) and the number of extra groups that were then rescored for them.  Every answer is exact either way; the
  * counters say how often the slow path ran (near-duplicate chunks).  Copies 16 bytes to the host and waits on `stream`. */
