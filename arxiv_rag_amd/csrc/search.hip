@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void fill_clustered_rows_kernel(f16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct TopkWs { int64_t stats, gmax, aux, part_s, part_g, q8, qmeta, thr, selg, counters, nsurv, redo, pairs, rpairs, surv_s, surv_i, total;
+struct TopkWs { int64_t stats, gmax, aux, part_s, part_g, q8, qmeta, qoff, thr, selg, counters, nsurv, redo, pairs, rpairs, surv_s, surv_i, total;
                 int64_t ldg; int nsplit; int64_t n_groups; };
 // has_i8: the layout arx_topk_search_i8 needs (aux word per (query, group), the quantised query batch, the candidate pipeline's lists:
 // about as much again as gmax + 64 KB per query); the fp16 pass reserves none of it.  Both layouts share their prefix
@@ -131,6 +131,7 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim, bool has_i8) {
     w.aux = take((has_i8 || (qb <= AUX16_MAX_NQ && n_super <= TAIL_INBLOCK_MAX_SUPER)) ? w.n_groups * w.ldg * 4 : 0);
     w.q8 = take8(w.ldg * (int64_t)dim);                          // the query batch quantised
     w.qmeta = take8(w.ldg * 8);
+    w.qoff = take8(w.ldg * 4);                                    // q . mu per query (the centred int8 index)
     const int64_t qc = qb;                                       // candidate pipeline state, sized by the internal query batch
     w.thr = take8(qc * 4);
     w.selg = take8(qc * KSEL_BIG * 4);
@@ -170,23 +171,23 @@ static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_row
 }
 
 template <int BM, bool GLDS>
-static int launch_groupmax_i8(const int8_t* Q8, const float2* qmeta, int nq, const int8_t* C8, const float2* cmeta, int64_t n_rows, int D,
+static int launch_groupmax_i8(const int8_t* Q8, const float2* qmeta, const float* qoff, int nq, const int8_t* C8, const float2* cmeta, int64_t n_rows, int D,
                               float* gmax, uint32_t* aux, int64_t ldg, hipStream_t st) {
     using ML = GemmMainloop<i8pair_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
     auto kern = search_groupmax_i8_kernel<BM, GLDS>;
-    constexpr int smem_bytes = ((BM == 256 && GLDS) ? Gemm8Phase<i8pair_t, 2>::STAGE_OFF : ML::SMEM_BYTES) + (BM >= 128 ? 4096 : 0);
+    constexpr int smem_bytes = ((BM == 256 && GLDS) ? Gemm8Phase<i8pair_t, 2>::STAGE_OFF : ML::SMEM_BYTES) + (BM >= 128 ? 6144 : 0);       // [512] + [2 BM] + [BM] floats behind the k-tile buffers
     ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem_bytes));
     const int tq = cdiv(nq, BM);
     const int64_t tn = (n_rows + 255) / 256;
     ARX_REQUIRE(tq * tn < (1ll << 31), "grid too large");
-    kern<<<(int)(tq * tn), 512, smem_bytes, st>>>(Q8, qmeta, nq, C8, cmeta, n_rows, D, tq, (int)tn, gmax, aux, ldg);
+    kern<<<(int)(tq * tn), 512, smem_bytes, st>>>(Q8, qmeta, qoff, nq, C8, cmeta, n_rows, D, tq, (int)tn, gmax, aux, ldg);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
 
 // pass A in persistent form: >= 256 queries per pass, an even number of 64-element k-tiles, rows addressable as int
 template <typename T, bool I8, bool AUX16 = false>
-static int launch_groupmax_persistent(const T* Q, int nq, const T* C, int64_t n_rows, int Kt, int D, const float2* qmeta, const float2* cmeta,
+static int launch_groupmax_persistent(const T* Q, int nq, const T* C, int64_t n_rows, int Kt, int D, const float2* qmeta, const float2* cmeta, const float* qoff,
                                       float* gmax, uint32_t* aux, int64_t ldg, int cu_limit, hipStream_t st,
                                       unsigned long long* zero_stats = nullptr) {
     auto kern = search_groupmax_persistent_kernel<T, I8, AUX16>;
@@ -198,7 +199,7 @@ static int launch_groupmax_persistent(const T* Q, int nq, const T* C, int64_t n_
     if (cu_limit > 0 && cu_limit < n_cu) n_cu = cu_limit;          // a CU-masked stream: one block per CU it may use
     int64_t grid = tq * tn < n_cu ? tq * tn : n_cu;
     grid = grid / 8 * 8 > 0 ? grid / 8 * 8 : 8;                   // a multiple of 8: a block keeps its XCD (and its residue class of corpus tiles)
-    kern<<<(int)grid, 512, smem_bytes, st>>>(Q, nq, C, n_rows, Kt, D, tq, (int)tn, qmeta, cmeta, gmax, aux, ldg, zero_stats);
+    kern<<<(int)grid, 512, smem_bytes, st>>>(Q, nq, C, n_rows, Kt, D, tq, (int)tn, qmeta, cmeta, qoff, gmax, aux, ldg, zero_stats);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -207,11 +208,13 @@ static bool persistent_pass_ok(int nq, int64_t n_rows, int k_elems, int flags) {
            (int64_t)k_elems * 2 * 256 < (1ll << 31);
 }
 
+// int8 index: [n_rows x dim int8] [n_rows x (scale, L1)] [dim floats: mu, the vector subtracted from every row before quantising it]
 static int64_t i8_meta_offset(int64_t n_rows, int dim) { return round_up64(n_rows * (int64_t)dim, 256); }
+static int64_t i8_mu_offset(int64_t n_rows, int dim) { return round_up64(i8_meta_offset(n_rows, dim) + n_rows * 8, 256); }
 
 extern "C" int64_t arx_topk_i8_index_bytes(int64_t n_rows, int32_t dim) {
     if (n_rows <= 0 || dim <= 0 || dim % 128 != 0 || dim > 1024) return -1;
-    return i8_meta_offset(n_rows, dim) + n_rows * 8;
+    return i8_mu_offset(n_rows, dim) + (int64_t)dim * 4;
 }
 
 extern "C" int32_t arx_topk_build_i8(const void* corpus, int64_t n_rows, int32_t dim, void* index_i8, void* stream) {
@@ -219,8 +222,12 @@ extern "C" int32_t arx_topk_build_i8(const void* corpus, int64_t n_rows, int32_t
     ARX_REQUIRE(dim % 128 == 0 && dim <= 1024, "int8 pre-filter: dim=%d must be a multiple of 128, <= 1024", dim);
     const int64_t blocks = (n_rows + 3) / 4;
     ARX_REQUIRE(blocks < (1ll << 31), "too many rows for one launch");
+    float* mu = (float*)((char*)index_i8 + i8_mu_offset(n_rows, dim));
+    rows_mean_kernel<<<cdiv(dim, 64), 256, 0, (hipStream_t)stream>>>((const f16_t*)corpus, n_rows, dim, mu);
+    ARX_HIP_CHECK(hipGetLastError());
     quantize_rows_i8_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)corpus, n_rows, dim, (int8_t*)index_i8,
-                                                                         (float2*)((char*)index_i8 + i8_meta_offset(n_rows, dim)), nullptr);
+                                                                         (float2*)((char*)index_i8 + i8_meta_offset(n_rows, dim)), nullptr, mu, nullptr,
+                                                                         nullptr);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -461,19 +468,21 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         } else if (use_i8) {                           // pass A over the int8 representation: upper bounds instead of scores, everything after it unchanged
             int8_t* q8 = (int8_t*)((char*)ws + L.q8);
             float2* qmeta = (float2*)((char*)ws + L.qmeta);
-            quantize_rows_i8_kernel<<<cdiv(nq, 4), 256, 0, st>>>(Q, nq, dim, q8, qmeta, q0 == 0 ? (unsigned long long*)((char*)ws + L.stats) : nullptr);
+            float* qoff = (float*)((char*)ws + L.qoff);
+            quantize_rows_i8_kernel<<<cdiv(nq, 4), 256, 0, st>>>(Q, nq, dim, q8, qmeta, q0 == 0 ? (unsigned long long*)((char*)ws + L.stats) : nullptr, nullptr,
+                                                                 (const float*)((const char*)index_i8 + i8_mu_offset(n_rows, dim)), qoff);
             ARX_HIP_CHECK(hipGetLastError());
             const int8_t* C8 = (const int8_t*)index_i8;
             const float2* cmeta = (const float2*)((const char*)index_i8 + i8_meta_offset(n_rows, dim));
             ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
             uint32_t* aux = (uint32_t*)((char*)ws + L.aux);
             if (persistent_pass_ok(nq, n_rows, dim / 2, P.flags))
-                rc = launch_groupmax_persistent<i8pair_t, true>((const i8pair_t*)q8, nq, (const i8pair_t*)C8, n_rows, dim / 2, dim, qmeta, cmeta, gmax,
+                rc = launch_groupmax_persistent<i8pair_t, true>((const i8pair_t*)q8, nq, (const i8pair_t*)C8, n_rows, dim / 2, dim, qmeta, cmeta, qoff, gmax,
                                                                 aux, L.ldg, P.cu_limit, st);
             else
-            rc = nq <= 64 ? launch_groupmax_i8<64, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
-               : nq <= 128 ? launch_groupmax_i8<128, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
-                           : launch_groupmax_i8<256, true>(q8, qmeta, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st);
+            rc = nq <= 64 ? launch_groupmax_i8<64, true>(q8, qmeta, qoff, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
+               : nq <= 128 ? launch_groupmax_i8<128, true>(q8, qmeta, qoff, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
+                           : launch_groupmax_i8<256, true>(q8, qmeta, qoff, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st);
         } else {
         ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
         uint32_t* aux16 = single ? (uint32_t*)((char*)ws + L.aux) : nullptr;                 // small fp16 batch: aux words for the single-kernel tail
@@ -486,8 +495,8 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         } else
 #endif
             if (persistent_pass_ok(nq, n_rows, dim, P.flags))
-                rc = single ? launch_groupmax_persistent<f16_t, false, true>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, gmax, aux16, L.ldg, P.cu_limit, st, zs16)
-                            : launch_groupmax_persistent<f16_t, false>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, gmax, nullptr, L.ldg, P.cu_limit, st);
+                rc = single ? launch_groupmax_persistent<f16_t, false, true>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, nullptr, gmax, aux16, L.ldg, P.cu_limit, st, zs16)
+                            : launch_groupmax_persistent<f16_t, false>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, nullptr, gmax, nullptr, L.ldg, P.cu_limit, st);
             else
             rc = nq <= 64 ? launch_groupmax<64, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)
                : nq <= 128 ? launch_groupmax<128, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)

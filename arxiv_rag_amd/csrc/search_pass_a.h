@@ -129,8 +129,10 @@ __device__ __forceinline__ uint32_t pack_aux(float ub2, int arg_row) {
 // X_c = s_c * (0.5001 L1(c8) + 0.2501 D) inflated by 2^-22 (its two roundings).  Three instructions per element (integer add,
 // convert — exact below 2^24 —, ONE fma = one rounding of the exact value); s_q > 0 and the rounding allowance are monotone, so
 // the group's two largest bounds are reduced FIRST and scaled / inflated afterwards, on two values instead of sixteen.
-template <int MI, int NI, typename CM, typename QM>
-__device__ __forceinline__ void groupmax_epilogue_i8(const f32x4 (&acc)[NI][MI], CM cm_of, QM qm_of, int D, float* __restrict__ gmax_row,
+//   qo_of(i): the query's OFFSET — an upper bound of q . mu, mu the vector the index subtracted from every row before quantising it (the
+//   shard's mean, arx_topk_build_i8): the int8 machinery bounds q . (c - mu), the offset makes it a bound of q . c again.
+template <int MI, int NI, typename CM, typename QM, typename QO>
+__device__ __forceinline__ void groupmax_epilogue_i8(const f32x4 (&acc)[NI][MI], CM cm_of, QM qm_of, QO qo_of, int D, float* __restrict__ gmax_row,
                                                      uint32_t* __restrict__ aux_row, int m_first, int nq, int lane) {
     float sc[NI][4], xc[NI][4];
     const float dterm = 0.2501f * (float)D;
@@ -180,6 +182,9 @@ __device__ __forceinline__ void groupmax_epilogue_i8(const f32x4 (&acc)[NI][MI],
         float b1 = m1 * qm.x, b2 = m2 * qm.x;
         b1 += fabsf(b1) * 8.0e-6f + 1e-12f;                              // 63 ulp of the index bits (2^-17.4) + the fma's and this product's roundings
         b2 += fabsf(b2) * 8.0e-6f + 1e-12f;
+        const float qo = qo_of(i);
+        b1 += qo; b2 += qo;                                              // + the offset (itself an upper bound); the additions' roundings:
+        b1 += fabsf(b1) * 1.2e-7f; b2 += fabsf(b2) * 1.2e-7f;
         gm[i] = b1; ga[i] = pack_aux(b2, i1);
     }
     store_query_row<MI, float>(gmax_row, gm, m_first, nq, lane);
@@ -194,10 +199,11 @@ struct MetaFromLds {
         c4[0] = float2{lo[0], lo[1]}; c4[1] = float2{lo[2], lo[3]}; c4[2] = float2{hi[0], hi[1]}; c4[3] = float2{hi[2], hi[3]};
     }
 };
-// one 4-byte LDS-DMA per thread stages the tile's corpus pairs, one more its query pairs (BM queries from m0)
+// one 4-byte LDS-DMA per thread stages the tile's corpus pairs, one more its query pairs (BM queries from m0), one more (threads < BM) the
+// queries' offsets: [512] [2 BM] [BM] floats
 template <int BM>
-__device__ __forceinline__ void stage_i8_meta(const float2* __restrict__ cmeta, const float2* __restrict__ qmeta, int64_t n0, int64_t n_rows,
-                                              int m0, int nq, float* meta, int tid) {
+__device__ __forceinline__ void stage_i8_meta(const float2* __restrict__ cmeta, const float2* __restrict__ qmeta, const float* __restrict__ qoff,
+                                              int64_t n0, int64_t n_rows, int m0, int nq, float* meta, int tid) {
     {
         int64_t e = n0 * 2 + tid;                                          // dword index into cmeta; rows past the shard repeat its last row
         const int64_t last = n_rows * 2 - 2 + (tid & 1);
@@ -209,6 +215,11 @@ __device__ __forceinline__ void stage_i8_meta(const float2* __restrict__ cmeta, 
         const int last = nq * 2 - 2 + (tid & 1);
         e = e < last ? e : last;
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const float*>(qmeta) + e), (lds_void_t*)(meta + 512 + (tid & ~63)), 4, 0, 0);
+    }
+    if (tid < BM) {                                                        // wave-uniform
+        int e = m0 + tid;
+        e = e < nq ? e : nq - 1;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(qoff + e), (lds_void_t*)(meta + 512 + 2 * BM + (tid & ~63)), 4, 0, 0);
     }
 }
 
@@ -263,8 +274,19 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
 // groupmax_epilogue_i8.  The certificate then reads: every unscored row's TRUE score <= U; U < s_k - tau => the answer is exact.  With
 // unit rows the slack is ~0.026, so ~150 groups per query reach the threshold; the candidate pipeline below (collect_pairs_kernel ->
 // pair_rescore_kernel -> merge_survivors_kernel) rescoring ONE row of almost every such group (aux word) settles them.
+//
+// CENTRED rows: every slack term above is proportional to s_c, i.e. to the largest |x_i| of the row that is quantised.  Rows that share a
+// large common component (anisotropic embeddings: the encoder's own rows under seeded weights have a mean pairwise cosine of 0.98) differ
+// from each other by much less than their own size, and a bound with unit-row slack cannot tell them apart.  The index therefore
+// quantises c - mu (mu: the mean of a sample of the shard's rows, `sub_mu`; ANY vector keeps the bound rigorous):
+//       q.c = q.mu + q.(c - mu) ,   fp32(c_i - mu_i) = (c_i - mu_i)(1 + d), |d| <= 2^-24: at most 127.5 s 2^-24 of the 0.0001 s allowance
+// and a QUERY batch gets, beside its int8 form, the offset q.mu rounded UP (`dot_mu` -> `qoff`; the fp32 chain's error is below
+// 18 roundings x 2^-24 relative to sum |q_i mu_i|), which pass A adds to every bound of that query.  On rows without a common component
+// mu ~ 0 and nothing changes.
 __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __restrict__ X, int64_t n_rows, int D, int8_t* __restrict__ X8,
-                                                                float2* __restrict__ meta, unsigned long long* __restrict__ zero_stats) {
+                                                                float2* __restrict__ meta, unsigned long long* __restrict__ zero_stats,
+                                                                const float* __restrict__ sub_mu, const float* __restrict__ dot_mu,
+                                                                float* __restrict__ qoff) {
     // (quantising a QUERY batch is the first kernel of an int8 search: the call's certificate counters start at zero here)
     if (zero_stats && blockIdx.x == 0 && threadIdx.x < 2) zero_stats[threadIdx.x] = 0ull;
     const int lane = threadIdx.x & 63;
@@ -279,7 +301,17 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __re
         f16_t h0, h1;
         __builtin_memcpy(&h0, &w2, 2); __builtin_memcpy(&h1, reinterpret_cast<const char*>(&w2) + 2, 2);
         v[e] = (float)h0; v[e + 1] = (float)h1;
+        if (sub_mu) { v[e] -= sub_mu[lane * per + e]; v[e + 1] -= sub_mu[lane * per + e + 1]; }
         amax = fmaxf(amax, fmaxf(fabsf(v[e]), fabsf(v[e + 1])));
+    }
+    if (dot_mu) {                                  // (a query row: its offset q . mu, rounded up)
+        float dot = 0.f, mag = 0.f;
+        for (int e = 0; e < per; ++e) {
+            const float m = dot_mu[lane * per + e];
+            dot = fmaf(v[e], m, dot); mag = fmaf(fabsf(v[e]), fabsf(m), mag);
+        }
+        dot = wave_sum(dot); mag = wave_sum(mag);
+        if (lane == 0) qoff[row] = dot + mag * 2.0e-6f + 1e-30f;
     }
     amax = wave_max(amax);
     const float s = amax / 127.0f;                 // an all-zero row: s = 0, every x8 = 0, upper bound 0
@@ -296,8 +328,29 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __re
     if (lane == 0) meta[row] = float2{s, l1};
 }
 
+// mu for the centred int8 index: the mean of up to MEAN_SAMPLE_ROWS evenly spaced rows, summed in a FIXED order (a block per 64 columns, a
+// wave per residue class of the sample, its rows in sequence, the four waves' sums added in order): the same shard always gives the same mu,
+// hence the same index and the same candidate lists.
+#define MEAN_SAMPLE_ROWS 16384
+__global__ __launch_bounds__(256) void rows_mean_kernel(const f16_t* __restrict__ X, int64_t n_rows, int D, float* __restrict__ mu) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int64_t S = n_rows < MEAN_SAMPLE_ROWS ? n_rows : MEAN_SAMPLE_ROWS;
+    float acc = 0.f;
+    if (col < D)
+        for (int64_t j = w; j < S; j += 4) {
+            const int64_t r = j * n_rows / S;
+            acc += (float)X[r * D + col];
+        }
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && col < D) mu[col] = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (float)S;
+}
+
 template <int BM, bool GLDS>
-__global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* __restrict__ Q8, const float2* __restrict__ qmeta, int nq,
+__global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* __restrict__ Q8, const float2* __restrict__ qmeta,
+                                                                  const float* __restrict__ qoff, int nq,
                                                                   const int8_t* __restrict__ C8, const float2* __restrict__ cmeta,
                                                                   int64_t n_rows, int D, int tiles_q, int tiles_n,
                                                                   float* __restrict__ gmax, uint32_t* __restrict__ aux, int64_t ldg) {
@@ -332,8 +385,9 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
     // k-tile — was built beside it and measured: +0-2 % at D = 768, +6-9 % at D = 384, -2 % for the fp16 rows; not kept.
     // profiles/r04/pass_a_narrow_int8_ab.md)
     float2 cmr = float2{0.f, 0.f}, qmr[META_LDS ? 1 : ML::MI];
+    float qor[META_LDS ? 1 : ML::MI];
     if constexpr (META_LDS) {
-        stage_i8_meta<BM>(cmeta, qmeta, n0, n_rows, m0, nq, meta, threadIdx.x);
+        stage_i8_meta<BM>(cmeta, qmeta, qoff, n0, n_rows, m0, nq, meta, threadIdx.x);
     } else {
         {
             const int t = lane & 15;
@@ -344,6 +398,7 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
         for (int i = 0; i < ML::MI; ++i) {
             const int m = m0 + wm * ML::TM + i * 16 + (lane & 15);
             qmr[i] = qmeta[m < nq ? m : nq - 1];
+            qor[i] = qoff[m < nq ? m : nq - 1];
         }
     }
     if constexpr (BM == 256 && GLDS) {
@@ -361,6 +416,7 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
         const float* qmeta_l = meta + 512 + (wm * ML::TM + (lane & 15)) * 2;
         groupmax_epilogue_i8<ML::MI, ML::NI>(acc, MetaFromLds{meta, wn, lrow},
                                              [&](int i) { return *reinterpret_cast<const float2*>(qmeta_l + i * 32); },
+                                             [&](int i) { return meta[512 + 2 * BM + wm * ML::TM + i * 16 + (lane & 15)]; },
                                              D, gmax + g * ldg, aux + g * ldg, m0 + wm * ML::TM, nq, lane);
     } else {
         groupmax_epilogue_i8<ML::MI, ML::NI>(acc, [&](int j, float2 (&c4)[4]) {
@@ -370,7 +426,8 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
                                                      c4[r] = float2{__shfl(cmr.x, src), __shfl(cmr.y, src)};
                                                  }
                                              },
-                                             [&](int i) { return qmr[i]; }, D, gmax + g * ldg, aux + g * ldg, m0 + wm * ML::TM, nq, lane);
+                                             [&](int i) { return qmr[i]; }, [&](int i) { return qor[i]; }, D, gmax + g * ldg, aux + g * ldg,
+                                             m0 + wm * ML::TM, nq, lane);
     }
 }
 
@@ -388,7 +445,7 @@ struct SearchTilePolicy {
     int64_t n_rows, ldg;
     float* gmax;
     uint32_t* aux;
-    const float2* qmeta; const float2* cmeta;
+    const float2* qmeta; const float2* cmeta; const float* qoff;
     __device__ __forceinline__ bool tile(int o, int& m0, int& n0, int& ko) const {
         const int x = o & 7, L = o >> 3;
         const int tq = L % tiles_q, tn = (L / tiles_q) * 8 + x;
@@ -396,7 +453,7 @@ struct SearchTilePolicy {
         return tn < tiles_n;
     }
     __device__ __forceinline__ void stage_issue(int m0, int n0, char* stage, int wid, int lane) const {
-        if constexpr (I8) stage_i8_meta<256>(cmeta, qmeta, n0, n_rows, m0, nq, reinterpret_cast<float*>(stage), wid * 64 + lane);
+        if constexpr (I8) stage_i8_meta<256>(cmeta, qmeta, qoff, n0, n_rows, m0, nq, reinterpret_cast<float*>(stage), wid * 64 + lane);
     }
     __device__ __forceinline__ void epilogue(const f32x4 (&acc)[4][8], int m0, int n0, int wr, int wc, int lane, const char* stage) const {
         if ((int64_t)n0 + wc * GROUP_ROWS >= n_rows) return;             // the wave's group lies past the shard (wave-uniform)
@@ -406,6 +463,7 @@ struct SearchTilePolicy {
             const float* qmeta_l = meta + 512 + (wr * 128 + (lane & 15)) * 2;
             groupmax_epilogue_i8<8, 4>(acc, MetaFromLds{meta, wc, (lane >> 4) * 4},
                                        [&](int i) { return *reinterpret_cast<const float2*>(qmeta_l + i * 32); },
+                                       [&](int i) { return meta[512 + 2 * 256 + wr * 128 + i * 16 + (lane & 15)]; },
                                        D, gmax + g * ldg, aux + g * ldg, m0 + wr * 128, nq, lane);
         } else if constexpr (AUX16)
             groupmax_epilogue_f16_aux<8, 4>(acc, gmax + g * ldg, aux + g * ldg, m0 + wr * 128, nq, lane);
@@ -421,10 +479,11 @@ template <typename T, bool I8, bool AUX16>
 __global__ __launch_bounds__(512) void search_groupmax_persistent_kernel(const T* __restrict__ Q, int nq, const T* __restrict__ C, int64_t n_rows,
                                                                           int Kt /* row length in T elements */, int D, int tiles_q, int tiles_n,
                                                                           const float2* __restrict__ qmeta, const float2* __restrict__ cmeta,
+                                                                          const float* __restrict__ qoff,
                                                                           float* __restrict__ gmax, uint32_t* __restrict__ aux, int64_t ldg,
                                                                           unsigned long long* __restrict__ zero_stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (zero_stats && blockIdx.x == 0 && threadIdx.x < 2) zero_stats[threadIdx.x] = 0ull;
-    const SearchTilePolicy<I8, AUX16> pol{tiles_q, tiles_n, nq, D, n_rows, ldg, gmax, aux, qmeta, cmeta};
+    const SearchTilePolicy<I8, AUX16> pol{tiles_q, tiles_n, nq, D, n_rows, ldg, gmax, aux, qmeta, cmeta, qoff};
     gemm8_persistent_body<T>(Q, Kt, C, Kt, nq, (int)n_rows, Kt, pol, smem);
 }

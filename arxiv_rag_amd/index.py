@@ -19,8 +19,9 @@ class ShardIndex:
     def __init__(self, corpus_f16: torch.Tensor, idx_base: int = 0, prefilter: Optional[str] = None, adaptive: bool = False,
                  i8_max_queries: Optional[int] = None, max_row_norm: Optional[float] = None):
         """`prefilter="int8"` (dim % 128 == 0, <= 1024): also keep an int8 representation of the rows (+50 % memory) and run the first
-        pass of every search over it — the same exact top-k (`arx_topk_search_i8`), 1.4-1.7x the queries per second on rows that
-        quantise well.  `adaptive=True` (the CLI and `HipCollection` pass it): the index reads the certificate counters after its
+        pass of every search over it — the same exact top-k (`arx_topk_search_i8`), 1.4-1.8x the queries per second on rows that
+        quantise well (the index quantises rows minus the shard's mean, so rows sharing a common component — mean pairwise cosine up to
+        ~0.75 measured — still do; profiles/r04/int8_centred_index.md).  `adaptive=True` (the CLI and `HipCollection` pass it): the index reads the certificate counters after its
         first searches (a 16-byte copy + stream sync each) and switches the pre-filter OFF for good when more than a quarter of a
         batch's queries overflowed their candidate lists — clustered / outlier-heavy rows on which the int8 bound is too slack to
         pay (answers are exact either way; this only picks the faster first pass).

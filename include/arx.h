@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ARX_VERSION 110            /* 0.1.1: search policy per call (arx_topk_options), no process-wide search state */
+#define ARX_VERSION 111            /* 0.1.1: search policy per call (arx_topk_options), no process-wide search state; 111: the int8 index is centred (layout + 4 dim bytes) */
 
 #define ARX_OK            0
 #define ARX_ERR_ARG      -1        /* bad argument / unsupported shape */
@@ -153,7 +153,8 @@ int32_t arx_topk_search(const void* corpus, int64_t n_rows, const void* queries,
                         void* ws, int64_t ws_bytes, void* stream);
 
 /* Optional int8 PRE-FILTER (no reference counterpart; same exact answers, fewer bytes).  arx_topk_build_i8 writes a second, int8
- * representation of the shard (row-wise scale + int8 values + the row's L1 norm: dim + 8 bytes per row, caller-owned device buffer of
+ * representation of the shard (int8 values of the rows MINUS a vector mu the build samples from them — their mean, so that rows sharing a large
+ * common component are told apart by what distinguishes them —, row-wise scale, the row's L1 norm, mu: dim + 8 bytes per row + 4 dim, caller-owned device buffer of
  * arx_topk_i8_index_bytes(...) bytes); arx_topk_search_i8 then runs its first pass over THAT — half the bytes where the pass is
  * HBM-bound, twice the MFMA rate where it is matrix-bound — computing for every (query, 64-row group) a rigorous UPPER BOUND on the
  * true fp16 score of the group's rows (quantisation error bounded analytically, csrc/search_pass_a.h).  Selection, the fp32 rescoring

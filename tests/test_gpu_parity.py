@@ -926,6 +926,41 @@ def test_search_int8_prefilter_on_clustered_anisotropic_rows(hip):
     assert torch.equal(i2, i) and torch.equal(s2, s)
 
 
+def test_int8_index_is_centred_rows_with_a_large_common_component_keep_the_prefilter(hip):
+    """Anisotropic embeddings (every row = a shared direction + an individual part; mean pairwise cosine 0.5 / 0.74 here — the range of
+    models like bge; the encoder's own rows under seeded weights are the extreme, 0.98) are hard for an int8 bound whose slack is
+    proportional to the size of the ROW: rows score within the slack of each other and most groups become candidates.  The index
+    quantises rows MINUS the shard's sampled mean (arx_topk_build_i8) and adds q . mean back per query, so the corpus side of the slack
+    is proportional to what distinguishes the rows.  Measured (tools/centred_debug.py, 192 k x 768, profiles/r04/int8_centred_index.md):
+    candidate (query, group) pairs per query 615 -> 215 at cosine 0.5; at 0.74 the un-centred index overflowed EVERY query (2 850 of the
+    3 000 groups) and the centred one 0-1 % of them (610).  Here: answers are the exact rows (against the fp16 pass, near-ties by fp32
+    scores), at most 2 % of the queries overflow, the adaptive index keeps the pre-filter ON."""
+    from arxiv_rag_amd.index import ShardIndex
+    F = torch.nn.functional
+    d, n = 768, 64 * 3000 + 17
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    u = torch.randn(d, generator=g, device="cuda"); u /= u.norm()
+    for amp, cos_lo, cos_hi, pair_cap in ((0.3, 0.45, 0.55, 450), (0.5, 0.70, 0.78, 1200)):
+        def rows(m):
+            return F.normalize(amp * u[None, :] + 0.3 * F.normalize(torch.randn((m, d), generator=g, device="cuda"), dim=1), dim=1).half()
+        C_ = rows(n); Q_ = rows(300)
+        cosm = float((C_[:512].float() @ C_[512:1024].float().T).mean().item())
+        assert cos_lo < cosm < cos_hi, cosm
+        ref = ShardIndex(C_, idx_base=5)
+        for nq in (1, 64, 300):
+            i8 = ShardIndex(C_, idx_base=5, prefilter="int8", adaptive=True)
+            a = i8.search(Q_[:nq], 10)
+            flagged, pairs = i8.certificate_stats()
+            b = ref.search(Q_[:nq], 10)
+            _assert_same_topk_up_to_ties(C_, Q_[:nq], a, b, idx_base=5)
+            assert not i8.prefilter_disabled and flagged <= max(1, nq // 50), (amp, nq, flagged)
+            assert pairs <= pair_cap * nq, (amp, nq, pairs)
+    # the offset is per QUERY: a batch mixing on-axis and off-axis queries (q . mean from ~0.85 down to ~0) is answered row for row
+    mix = torch.cat([Q_[:8], F.normalize(torch.randn((8, d), generator=g, device="cuda"), dim=1).half()])
+    i8 = ShardIndex(C_, prefilter="int8")
+    _assert_same_topk_up_to_ties(C_, mix, i8.search(mix, 10), ShardIndex(C_).search(mix, 10))
+
+
 def test_int8_index_follows_writes_to_the_corpus(hip):
     """the int8 copy is a snapshot; rows written afterwards (ShardSink.put, the encoder) must not be searched through
     stale int8 values.  The index notices the tensor's version counter and rebuilds."""

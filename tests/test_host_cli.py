@@ -359,7 +359,7 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/arx.h but not exported"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     bound = _lib.load()
-    assert bound.arx_version() == 110
+    assert bound.arx_version() == 111
     # host-only entry point: MPNet bucket table vs the golden (transformers) values — no GPU involved
     g = np.load(ROOT / "tests" / "golden" / "mpnet_tables.npz")
     got = np.array([bound.arx_mpnet_bucket(int(d), 32, 128) for d in g["delta"]])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Race / edge screen of the search path (the counterpart of tools/gemm_soak.py): random shard sizes (1 row ... a few hundred thousand, ragged
 against every tile size), dimensions, query-batch sizes (1 ... 1 100: narrow tiles, the persistent pass, two internal passes), k, first pass
-(fp16 / int8), row norms (unit / 0.01 ... 8), planted near-ties and duplicated rows, idx_base; every answer validated ON THE DEVICE against
+(fp16 / int8), row norms (unit / 0.01 ... 8), a component shared by all rows (anisotropic embeddings), planted near-ties and duplicated rows, idx_base; every answer validated ON THE DEVICE against
 fp32 scores of EVERY row (returned scores are those rows' scores; nothing left out beats the k-th by more than the tolerance; equal scores in
 ascending id order), run twice (bit-repeatable), and — batches of <= 1 024 queries — against `search_many` (2 lanes).
 usage: search_soak.py [seconds] [seed]"""
@@ -63,6 +63,10 @@ while time.time() - t0 < secs:
     base = [0, 7, 1 << 33][ri(0, 2)]
     c = torch.nn.functional.normalize(torch.randn((n, d), generator=g, device="cuda"), dim=1)
     q = torch.nn.functional.normalize(torch.randn((nq, d), generator=g, device="cuda"), dim=1)
+    if ri(0, 3) == 0:                                                # a common component (anisotropic embeddings; the int8 index is centred on the shard's mean)
+        u = torch.nn.functional.normalize(torch.randn((1, d), generator=g, device="cuda"), dim=1) * [0.2, 0.6, 1.5, -0.8][ri(0, 3)]
+        c = torch.nn.functional.normalize(c + u, dim=1)
+        q = torch.nn.functional.normalize(q + (u if ri(0, 1) else 0.3 * u), dim=1)
     scale = 1.0
     if ri(0, 3) == 0:                                                # rows far from unit norm
         nr = torch.exp(torch.empty(n, device="cuda").uniform_(-4.6, 2.08, generator=g)); c = c * nr[:, None]; scale = float(nr.max().item())
