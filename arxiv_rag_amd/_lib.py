@@ -41,7 +41,7 @@ class TopkOptionsC(C.Structure):
         self.struct_bytes = C.sizeof(TopkOptionsC)
 
 
-TOPK_NO_PERSISTENT, TOPK_SCAN_ONLY, TOPK_TAIL_ONLY, TOPK_NO_SINGLE_ROW_TAIL = 1, 2, 4, 8
+TOPK_NO_PERSISTENT, TOPK_SCAN_ONLY, TOPK_TAIL_ONLY, TOPK_NO_SINGLE_ROW_TAIL, TOPK_I8_CENTRE_QUERY = 1, 2, 4, 8, 16
 
 
 EXPORTS = {
@@ -64,6 +64,7 @@ EXPORTS = {
     "arx_topk_search": (C.c_int32, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "arx_topk_i8_index_bytes": (C.c_int64, [C.c_int64, C.c_int32]),
+    "arx_topk_i8_index_info": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_float), C.c_void_p]),
     "arx_topk_build_i8": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "arx_topk_search_i8": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),

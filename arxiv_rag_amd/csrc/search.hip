@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void fill_clustered_rows_kernel(f16_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-struct TopkWs { int64_t stats, gmax, aux, part_s, part_g, q8, qmeta, qoff, thr, selg, counters, nsurv, redo, pairs, rpairs, surv_s, surv_i, total;
+struct TopkWs { int64_t stats, gmax, aux, part_s, part_g, q8, qmeta, qoff, qg, thr, selg, counters, nsurv, redo, pairs, rpairs, surv_s, surv_i, total;
                 int64_t ldg; int nsplit; int64_t n_groups; };
 // has_i8: the layout arx_topk_search_i8 needs (aux word per (query, group), the quantised query batch, the candidate pipeline's lists:
 // about as much again as gmax + 64 KB per query); the fp16 pass reserves none of it.  Both layouts share their prefix
@@ -132,6 +132,7 @@ static TopkWs topk_layout(int64_t n_rows, int nq, int k, int dim, bool has_i8) {
     w.q8 = take8(w.ldg * (int64_t)dim);                          // the query batch quantised
     w.qmeta = take8(w.ldg * 8);
     w.qoff = take8(w.ldg * 4);                                    // q . mu per query (the centred int8 index)
+    w.qg = take8(w.ldg * 4);                                      // gamma / s_q per query (ARX_TOPK_I8_CENTRE_QUERY)
     const int64_t qc = qb;                                       // candidate pipeline state, sized by the internal query batch
     w.thr = take8(qc * 4);
     w.selg = take8(qc * KSEL_BIG * 4);
@@ -170,27 +171,29 @@ static int launch_groupmax(const f16_t* Q, int nq, const f16_t* C, int64_t n_row
     return ARX_OK;
 }
 
-template <int BM, bool GLDS>
-static int launch_groupmax_i8(const int8_t* Q8, const float2* qmeta, const float* qoff, int nq, const int8_t* C8, const float2* cmeta, int64_t n_rows, int D,
+template <int BM, bool GLDS, bool R1>
+static int launch_groupmax_i8(const int8_t* Q8, const float2* qmeta, const float* qoff, const float* qg, int nq, const int8_t* C8, const float2* cmeta,
+                              const float* ctrow, int64_t n_rows, int D,
                               float* gmax, uint32_t* aux, int64_t ldg, hipStream_t st) {
     using ML = GemmMainloop<i8pair_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
-    auto kern = search_groupmax_i8_kernel<BM, GLDS>;
-    constexpr int smem_bytes = ((BM == 256 && GLDS) ? Gemm8Phase<i8pair_t, 2>::STAGE_OFF : ML::SMEM_BYTES) + (BM >= 128 ? 6144 : 0);       // [512] + [2 BM] + [BM] floats behind the k-tile buffers
+    auto kern = search_groupmax_i8_kernel<BM, GLDS, R1>;
+    constexpr int smem_bytes = ((BM == 256 && GLDS) ? Gemm8Phase<i8pair_t, 2>::STAGE_OFF : ML::SMEM_BYTES) + (BM >= 128 ? 7168 : 0);       // stage_i8_meta's [768 + 4 BM] floats behind the k-tile buffers
     ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem_bytes));
     const int tq = cdiv(nq, BM);
     const int64_t tn = (n_rows + 255) / 256;
     ARX_REQUIRE(tq * tn < (1ll << 31), "grid too large");
-    kern<<<(int)(tq * tn), 512, smem_bytes, st>>>(Q8, qmeta, qoff, nq, C8, cmeta, n_rows, D, tq, (int)tn, gmax, aux, ldg);
+    kern<<<(int)(tq * tn), 512, smem_bytes, st>>>(Q8, qmeta, qoff, qg, nq, C8, cmeta, ctrow, n_rows, D, tq, (int)tn, gmax, aux, ldg);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
 
 // pass A in persistent form: >= 256 queries per pass, an even number of 64-element k-tiles, rows addressable as int
-template <typename T, bool I8, bool AUX16 = false>
+template <typename T, bool I8, bool AUX16 = false, bool R1 = false>
 static int launch_groupmax_persistent(const T* Q, int nq, const T* C, int64_t n_rows, int Kt, int D, const float2* qmeta, const float2* cmeta, const float* qoff,
+                                      const float* qg, const float* ctrow,
                                       float* gmax, uint32_t* aux, int64_t ldg, int cu_limit, hipStream_t st,
                                       unsigned long long* zero_stats = nullptr) {
-    auto kern = search_groupmax_persistent_kernel<T, I8, AUX16>;
+    auto kern = search_groupmax_persistent_kernel<T, I8, AUX16, R1>;
     constexpr int smem_bytes = Gemm8Phase<T, 0>::SMEM_BYTES;
     ARX_HIP_CHECK(arx_func_smem((const void*)kern, smem_bytes));
     const int tq = cdiv(nq, 256);
@@ -199,7 +202,7 @@ static int launch_groupmax_persistent(const T* Q, int nq, const T* C, int64_t n_
     if (cu_limit > 0 && cu_limit < n_cu) n_cu = cu_limit;          // a CU-masked stream: one block per CU it may use
     int64_t grid = tq * tn < n_cu ? tq * tn : n_cu;
     grid = grid / 8 * 8 > 0 ? grid / 8 * 8 : 8;                   // a multiple of 8: a block keeps its XCD (and its residue class of corpus tiles)
-    kern<<<(int)grid, 512, smem_bytes, st>>>(Q, nq, C, n_rows, Kt, D, tq, (int)tn, qmeta, cmeta, qoff, gmax, aux, ldg, zero_stats);
+    kern<<<(int)grid, 512, smem_bytes, st>>>(Q, nq, C, n_rows, Kt, D, tq, (int)tn, qmeta, cmeta, qoff, qg, ctrow, gmax, aux, ldg, zero_stats);
     ARX_HIP_CHECK(hipGetLastError());
     return ARX_OK;
 }
@@ -208,13 +211,17 @@ static bool persistent_pass_ok(int nq, int64_t n_rows, int k_elems, int flags) {
            (int64_t)k_elems * 2 * 256 < (1ll << 31);
 }
 
-// int8 index: [n_rows x dim int8] [n_rows x (scale, L1)] [dim floats: mu, the vector subtracted from every row before quantising it]
+// int8 index: [n_rows x dim int8] [n_rows x (scale, L1)] [n_rows floats: t_c = m^ . (c - mu)] [dim floats: mu, the vector subtracted from every
+// row before quantising it] [dim floats: m^ = mu / |mu|] [I8Header: |mu|, max |t_c|, max sum |c'_i m^_i|]
 static int64_t i8_meta_offset(int64_t n_rows, int dim) { return round_up64(n_rows * (int64_t)dim, 256); }
-static int64_t i8_mu_offset(int64_t n_rows, int dim) { return round_up64(i8_meta_offset(n_rows, dim) + n_rows * 8, 256); }
+static int64_t i8_t_offset(int64_t n_rows, int dim) { return round_up64(i8_meta_offset(n_rows, dim) + n_rows * 8, 256); }
+static int64_t i8_mu_offset(int64_t n_rows, int dim) { return round_up64(i8_t_offset(n_rows, dim) + n_rows * 4, 256); }
+static int64_t i8_mhat_offset(int64_t n_rows, int dim) { return i8_mu_offset(n_rows, dim) + (int64_t)dim * 4; }
+static int64_t i8_hdr_offset(int64_t n_rows, int dim) { return i8_mhat_offset(n_rows, dim) + (int64_t)dim * 4; }
 
 extern "C" int64_t arx_topk_i8_index_bytes(int64_t n_rows, int32_t dim) {
     if (n_rows <= 0 || dim <= 0 || dim % 128 != 0 || dim > 1024) return -1;
-    return i8_mu_offset(n_rows, dim) + (int64_t)dim * 4;
+    return i8_hdr_offset(n_rows, dim) + 256;
 }
 
 extern "C" int32_t arx_topk_build_i8(const void* corpus, int64_t n_rows, int32_t dim, void* index_i8, void* stream) {
@@ -223,12 +230,24 @@ extern "C" int32_t arx_topk_build_i8(const void* corpus, int64_t n_rows, int32_t
     const int64_t blocks = (n_rows + 3) / 4;
     ARX_REQUIRE(blocks < (1ll << 31), "too many rows for one launch");
     float* mu = (float*)((char*)index_i8 + i8_mu_offset(n_rows, dim));
+    float* mhat = (float*)((char*)index_i8 + i8_mhat_offset(n_rows, dim));
+    I8Header* hdr = (I8Header*)((char*)index_i8 + i8_hdr_offset(n_rows, dim));
     rows_mean_kernel<<<cdiv(dim, 64), 256, 0, (hipStream_t)stream>>>((const f16_t*)corpus, n_rows, dim, mu);
+    ARX_HIP_CHECK(hipGetLastError());
+    mean_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(mu, dim, mhat, hdr);
     ARX_HIP_CHECK(hipGetLastError());
     quantize_rows_i8_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const f16_t*)corpus, n_rows, dim, (int8_t*)index_i8,
                                                                          (float2*)((char*)index_i8 + i8_meta_offset(n_rows, dim)), nullptr, mu, nullptr,
-                                                                         nullptr);
+                                                                         nullptr, mhat, (float*)((char*)index_i8 + i8_t_offset(n_rows, dim)), hdr, nullptr,
+                                                                         nullptr, 0);
     ARX_HIP_CHECK(hipGetLastError());
+    return ARX_OK;
+}
+
+extern "C" int32_t arx_topk_i8_index_info(const void* index_i8, int64_t n_rows, int32_t dim, float* host_out, void* stream) {
+    ARX_REQUIRE(index_i8 && host_out && n_rows > 0 && dim > 0 && dim % 128 == 0 && dim <= 1024, "bad args");
+    ARX_HIP_CHECK(hipMemcpyAsync(host_out, (const char*)index_i8 + i8_hdr_offset(n_rows, dim), 3 * sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ARX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     return ARX_OK;
 }
 
@@ -469,20 +488,30 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
             int8_t* q8 = (int8_t*)((char*)ws + L.q8);
             float2* qmeta = (float2*)((char*)ws + L.qmeta);
             float* qoff = (float*)((char*)ws + L.qoff);
+            float* qg = (float*)((char*)ws + L.qg);
+            const bool r1 = (P.flags & ARX_TOPK_I8_CENTRE_QUERY) != 0;          // the query is centred too; pass A adds the rank-one term (search_pass_a.h)
+            const float* ctrow = (const float*)((const char*)index_i8 + i8_t_offset(n_rows, dim));
             quantize_rows_i8_kernel<<<cdiv(nq, 4), 256, 0, st>>>(Q, nq, dim, q8, qmeta, q0 == 0 ? (unsigned long long*)((char*)ws + L.stats) : nullptr, nullptr,
-                                                                 (const float*)((const char*)index_i8 + i8_mu_offset(n_rows, dim)), qoff);
+                                                                 (const float*)((const char*)index_i8 + i8_mu_offset(n_rows, dim)), qoff,
+                                                                 (const float*)((const char*)index_i8 + i8_mhat_offset(n_rows, dim)), nullptr, nullptr,
+                                                                 (const I8Header*)((const char*)index_i8 + i8_hdr_offset(n_rows, dim)), qg, r1 ? 1 : 0);
             ARX_HIP_CHECK(hipGetLastError());
             const int8_t* C8 = (const int8_t*)index_i8;
             const float2* cmeta = (const float2*)((const char*)index_i8 + i8_meta_offset(n_rows, dim));
             ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
             uint32_t* aux = (uint32_t*)((char*)ws + L.aux);
             if (persistent_pass_ok(nq, n_rows, dim / 2, P.flags))
-                rc = launch_groupmax_persistent<i8pair_t, true>((const i8pair_t*)q8, nq, (const i8pair_t*)C8, n_rows, dim / 2, dim, qmeta, cmeta, qoff, gmax,
-                                                                aux, L.ldg, P.cu_limit, st);
+                rc = r1 ? launch_groupmax_persistent<i8pair_t, true, false, true>((const i8pair_t*)q8, nq, (const i8pair_t*)C8, n_rows, dim / 2, dim, qmeta, cmeta,
+                                                                                   qoff, qg, ctrow, gmax, aux, L.ldg, P.cu_limit, st)
+                        : launch_groupmax_persistent<i8pair_t, true>((const i8pair_t*)q8, nq, (const i8pair_t*)C8, n_rows, dim / 2, dim, qmeta, cmeta, qoff,
+                                                                     nullptr, nullptr, gmax, aux, L.ldg, P.cu_limit, st);
             else
-            rc = nq <= 64 ? launch_groupmax_i8<64, true>(q8, qmeta, qoff, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
-               : nq <= 128 ? launch_groupmax_i8<128, true>(q8, qmeta, qoff, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st)
-                           : launch_groupmax_i8<256, true>(q8, qmeta, qoff, nq, C8, cmeta, n_rows, dim, gmax, aux, L.ldg, st);
+            rc = r1 ? (nq <= 64 ? launch_groupmax_i8<64, true, true>(q8, qmeta, qoff, qg, nq, C8, cmeta, ctrow, n_rows, dim, gmax, aux, L.ldg, st)
+                       : nq <= 128 ? launch_groupmax_i8<128, true, true>(q8, qmeta, qoff, qg, nq, C8, cmeta, ctrow, n_rows, dim, gmax, aux, L.ldg, st)
+                                   : launch_groupmax_i8<256, true, true>(q8, qmeta, qoff, qg, nq, C8, cmeta, ctrow, n_rows, dim, gmax, aux, L.ldg, st))
+                    : (nq <= 64 ? launch_groupmax_i8<64, true, false>(q8, qmeta, qoff, qg, nq, C8, cmeta, ctrow, n_rows, dim, gmax, aux, L.ldg, st)
+                       : nq <= 128 ? launch_groupmax_i8<128, true, false>(q8, qmeta, qoff, qg, nq, C8, cmeta, ctrow, n_rows, dim, gmax, aux, L.ldg, st)
+                                   : launch_groupmax_i8<256, true, false>(q8, qmeta, qoff, qg, nq, C8, cmeta, ctrow, n_rows, dim, gmax, aux, L.ldg, st));
         } else {
         ProfScope ps(ARX_K_SEARCH_GROUPMAX, st);
         uint32_t* aux16 = single ? (uint32_t*)((char*)ws + L.aux) : nullptr;                 // small fp16 batch: aux words for the single-kernel tail
@@ -495,8 +524,8 @@ static int topk_search_impl(const void* corpus, const void* index_i8, int64_t n_
         } else
 #endif
             if (persistent_pass_ok(nq, n_rows, dim, P.flags))
-                rc = single ? launch_groupmax_persistent<f16_t, false, true>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, nullptr, gmax, aux16, L.ldg, P.cu_limit, st, zs16)
-                            : launch_groupmax_persistent<f16_t, false>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, nullptr, gmax, nullptr, L.ldg, P.cu_limit, st);
+                rc = single ? launch_groupmax_persistent<f16_t, false, true>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, nullptr, nullptr, nullptr, gmax, aux16, L.ldg, P.cu_limit, st, zs16)
+                            : launch_groupmax_persistent<f16_t, false>(Q, nq, C, n_rows, dim, dim, nullptr, nullptr, nullptr, nullptr, nullptr, gmax, nullptr, L.ldg, P.cu_limit, st);
             else
             rc = nq <= 64 ? launch_groupmax<64, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)
                : nq <= 128 ? launch_groupmax<128, true>(Q, nq, C, n_rows, dim, gmax, L.ldg, aux16, zs16, st)

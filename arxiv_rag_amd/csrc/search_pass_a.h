@@ -131,10 +131,12 @@ __device__ __forceinline__ uint32_t pack_aux(float ub2, int arg_row) {
 // the group's two largest bounds are reduced FIRST and scaled / inflated afterwards, on two values instead of sixteen.
 //   qo_of(i): the query's OFFSET — an upper bound of q . mu, mu the vector the index subtracted from every row before quantising it (the
 //   shard's mean, arx_topk_build_i8): the int8 machinery bounds q . (c - mu), the offset makes it a bound of q . c again.
-template <int MI, int NI, typename CM, typename QM, typename QO>
-__device__ __forceinline__ void groupmax_epilogue_i8(const f32x4 (&acc)[NI][MI], CM cm_of, QM qm_of, QO qo_of, int D, float* __restrict__ gmax_row,
-                                                     uint32_t* __restrict__ aux_row, int m_first, int nq, int lane) {
-    float sc[NI][4], xc[NI][4];
+//   R1 (the query was centred too, ARX_TOPK_I8_CENTRE_QUERY): ct_of(j, t4) gives t_c = m^ . (c - mu) of the lane's rows, qg_of(i) the
+//   query's gamma / s_q; one more fma per element adds the rank-one term gamma t_c (see quantize_rows_i8_kernel).
+template <int MI, int NI, bool R1, typename CM, typename QM, typename QO, typename CT, typename QG>
+__device__ __forceinline__ void groupmax_epilogue_i8(const f32x4 (&acc)[NI][MI], CM cm_of, QM qm_of, QO qo_of, CT ct_of, QG qg_of, int D,
+                                                     float* __restrict__ gmax_row, uint32_t* __restrict__ aux_row, int m_first, int nq, int lane) {
+    float sc[NI][4], xc[NI][4], tc[R1 ? NI : 1][4];
     const float dterm = 0.2501f * (float)D;
     const int lrow = (lane >> 4) * 4;
 #pragma unroll
@@ -147,6 +149,7 @@ __device__ __forceinline__ void groupmax_epilogue_i8(const f32x4 (&acc)[NI][MI],
             const float x = c4[r].x * fmaf(0.5001f, c4[r].y, dterm);
             xc[j][r] = fmaf(x, 2.4e-7f, x);
         }
+        if constexpr (R1) ct_of(j, tc[j]);
     }
     float gm[MI];
     uint32_t ga[MI];
@@ -154,6 +157,8 @@ __device__ __forceinline__ void groupmax_epilogue_i8(const f32x4 (&acc)[NI][MI],
     for (int i = 0; i < MI; ++i) {
         const float2 qm = qm_of(i);
         const int cqi = (int)ceilf(0.5001f * qm.y) + 1;
+        float gq = 0.f;
+        if constexpr (R1) gq = qg_of(i);
         // top-2 of the 16 bounds with the arg-max for free: the low 6 bits of each value's float image are REPLACED by the row's
         // position in the group (j*16 + r; the lane's 4-row offset is OR-ed in after the lane-local pass), which moves a value by at
         // most 63 ulp either way — covered by the 2^-17 allowance below — and lets v_max / v_med3 carry the index along.
@@ -163,7 +168,8 @@ __device__ __forceinline__ void groupmax_epilogue_i8(const f32x4 (&acc)[NI][MI],
             const i32x4 it = __builtin_bit_cast(i32x4, acc[j][i]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float u = fmaf(sc[j][r], (float)(it[r] + cqi), xc[j][r]);
+                float u = fmaf(sc[j][r], (float)(it[r] + cqi), xc[j][r]);
+                if constexpr (R1) u = fmaf(gq, tc[j][r], u);
                 const float key = __uint_as_float((__float_as_uint(u) & ~63u) | (uint32_t)(j * 16 + r));
                 m2 = __builtin_amdgcn_fmed3f(m1, m2, key);               // second largest of {m1 >= m2, key}
                 m1 = fmaxf(m1, key);
@@ -199,10 +205,20 @@ struct MetaFromLds {
         c4[0] = float2{lo[0], lo[1]}; c4[1] = float2{lo[2], lo[3]}; c4[2] = float2{hi[0], hi[1]}; c4[3] = float2{hi[2], hi[3]};
     }
 };
+struct TFromLds {                                    // t_c of the lane's rows: [256 floats] behind the corpus pairs
+    const float* meta; int wn, lrow;
+    __device__ __forceinline__ void operator()(int j, float (&t4)[4]) const {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(meta + 512 + wn * GROUP_ROWS + j * 16 + lrow);
+        t4[0] = v[0]; t4[1] = v[1]; t4[2] = v[2]; t4[3] = v[3];
+    }
+};
+struct NoT { __device__ __forceinline__ void operator()(int, float (&)[4]) const {} };
+#define I8_META_Q_OFF 768                            // LDS stage: [512] corpus (s, L1) pairs, [256] corpus t, then the queries' [2 BM] pairs, [BM] offsets, [BM] gamma / s_q
 // one 4-byte LDS-DMA per thread stages the tile's corpus pairs, one more its query pairs (BM queries from m0), one more (threads < BM) the
-// queries' offsets: [512] [2 BM] [BM] floats
-template <int BM>
-__device__ __forceinline__ void stage_i8_meta(const float2* __restrict__ cmeta, const float2* __restrict__ qmeta, const float* __restrict__ qoff,
+// queries' offsets; R1: also the rows' t and the queries' gamma / s_q
+template <int BM, bool R1>
+__device__ __forceinline__ void stage_i8_meta(const float2* __restrict__ cmeta, const float* __restrict__ ctrow, const float2* __restrict__ qmeta,
+                                              const float* __restrict__ qoff, const float* __restrict__ qg,
                                               int64_t n0, int64_t n_rows, int m0, int nq, float* meta, int tid) {
     {
         int64_t e = n0 * 2 + tid;                                          // dword index into cmeta; rows past the shard repeat its last row
@@ -214,12 +230,21 @@ __device__ __forceinline__ void stage_i8_meta(const float2* __restrict__ cmeta, 
         int e = m0 * 2 + tid;
         const int last = nq * 2 - 2 + (tid & 1);
         e = e < last ? e : last;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const float*>(qmeta) + e), (lds_void_t*)(meta + 512 + (tid & ~63)), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(reinterpret_cast<const float*>(qmeta) + e), (lds_void_t*)(meta + I8_META_Q_OFF + (tid & ~63)), 4, 0, 0);
     }
     if (tid < BM) {                                                        // wave-uniform
         int e = m0 + tid;
         e = e < nq ? e : nq - 1;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(qoff + e), (lds_void_t*)(meta + 512 + 2 * BM + (tid & ~63)), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(qoff + e), (lds_void_t*)(meta + I8_META_Q_OFF + 2 * BM + (tid & ~63)), 4, 0, 0);
+        if constexpr (R1)
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(qg + e), (lds_void_t*)(meta + I8_META_Q_OFF + 3 * BM + (tid & ~63)), 4, 0, 0);
+    }
+    if constexpr (R1) {
+        if (tid < 256) {
+            int64_t e = n0 + tid;
+            e = e < n_rows ? e : n_rows - 1;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)(ctrow + e), (lds_void_t*)(meta + 512 + (tid & ~63)), 4, 0, 0);
+        }
     }
 }
 
@@ -283,10 +308,24 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
 // and a QUERY batch gets, beside its int8 form, the offset q.mu rounded UP (`dot_mu` -> `qoff`; the fp32 chain's error is below
 // 18 roundings x 2^-24 relative to sum |q_i mu_i|), which pass A adds to every bound of that query.  On rows without a common component
 // mu ~ 0 and nothing changes.
+//
+// CENTRED QUERIES (ARX_TOPK_I8_CENTRE_QUERY; the caller's choice per call, sensible when |mu| is large): the slack terms proportional to the
+// QUERY's quantisation step and L1 norm still see the whole query.  For any unit-ish vector m^ (the index keeps mu / |mu|) and scalar gamma
+//       q.(c - mu) = gamma t_c + (q - gamma m^).(c - mu) ,   t_c = m^.(c - mu)   (an identity in real arithmetic),
+// so with gamma = q.m^ the query that is quantised is q' = q - gamma m^ (what distinguishes it from the common direction), the int8
+// machinery bounds q'.(c - mu), and the rank-one term gamma t_c — neither a per-query nor a per-row constant — is added EXACTLY per element
+// in pass A's epilogue (one fma with gamma / s_q and the row's t_c, which the index stores).  Roundings: q'_i = fma(-gamma, m^_i, q_i) is one
+// rounding of the exact value (inside the 0.0001 s_q allowance, as for the rows); t_c as computed differs from m^.(c - mu) by at most
+// 2.2e-6 sum |c'_i m^_i| <= 2.2e-6 E (E: the largest such sum over the shard, kept in the index header), gamma / s_q and the epilogue's fma
+// add 2.4e-7 |gamma| T (T: the largest |t_c|): both go into the query's offset.  A query that IS the common direction (q' = 0, s_q = 0) gets
+// |gamma| T in its offset instead of the rank-one term.
+struct I8Header { float mu_norm, t_max, e_max, pad; };
 __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __restrict__ X, int64_t n_rows, int D, int8_t* __restrict__ X8,
                                                                 float2* __restrict__ meta, unsigned long long* __restrict__ zero_stats,
                                                                 const float* __restrict__ sub_mu, const float* __restrict__ dot_mu,
-                                                                float* __restrict__ qoff) {
+                                                                float* __restrict__ qoff, const float* __restrict__ mhat,
+                                                                float* __restrict__ trow, I8Header* __restrict__ hdr_w,
+                                                                const I8Header* __restrict__ hdr_r, float* __restrict__ qg, int centre_q) {
     // (quantising a QUERY batch is the first kernel of an int8 search: the call's certificate counters start at zero here)
     if (zero_stats && blockIdx.x == 0 && threadIdx.x < 2) zero_stats[threadIdx.x] = 0ull;
     const int lane = threadIdx.x & 63;
@@ -304,6 +343,20 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __re
         if (sub_mu) { v[e] -= sub_mu[lane * per + e]; v[e + 1] -= sub_mu[lane * per + e + 1]; }
         amax = fmaxf(amax, fmaxf(fabsf(v[e]), fabsf(v[e + 1])));
     }
+    float off = 0.f, gamma = 0.f;
+    if (trow) {                                    // (a corpus row, already minus mu: its t_c = m^ . c' for centred queries, and the header's maxima)
+        float t = 0.f, mag = 0.f;
+        for (int e = 0; e < per; ++e) {
+            const float m = mhat[lane * per + e];
+            t = fmaf(v[e], m, t); mag = fmaf(fabsf(v[e]), fabsf(m), mag);
+        }
+        t = wave_sum(t); mag = wave_sum(mag);
+        if (lane == 0) {
+            trow[row] = t;
+            atomicMax(reinterpret_cast<unsigned int*>(&hdr_w->t_max), __float_as_uint(fabsf(t)));      // non-negative floats order as their bit patterns
+            atomicMax(reinterpret_cast<unsigned int*>(&hdr_w->e_max), __float_as_uint(mag));
+        }
+    }
     if (dot_mu) {                                  // (a query row: its offset q . mu, rounded up)
         float dot = 0.f, mag = 0.f;
         for (int e = 0; e < per; ++e) {
@@ -311,7 +364,18 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __re
             dot = fmaf(v[e], m, dot); mag = fmaf(fabsf(v[e]), fabsf(m), mag);
         }
         dot = wave_sum(dot); mag = wave_sum(mag);
-        if (lane == 0) qoff[row] = dot + mag * 2.0e-6f + 1e-30f;
+        off = dot + mag * 2.0e-6f + 1e-30f;
+        if (centre_q) {                            // q' = q - gamma m^ is what gets quantised
+            float g = 0.f;
+            for (int e = 0; e < per; ++e) g = fmaf(v[e], mhat[lane * per + e], g);
+            gamma = wave_sum(g);
+            amax = 0.f;
+            for (int e = 0; e < per; ++e) {
+                v[e] = fmaf(-gamma, mhat[lane * per + e], v[e]);
+                amax = fmaxf(amax, fabsf(v[e]));
+            }
+            off += fabsf(gamma) * (2.2e-6f * hdr_r->e_max + 2.4e-7f * hdr_r->t_max);
+        }
     }
     amax = wave_max(amax);
     const float s = amax / 127.0f;                 // an all-zero row: s = 0, every x8 = 0, upper bound 0
@@ -325,7 +389,14 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __re
         *reinterpret_cast<uint16_t*>(o + e) = pk;
     }
     l1 = wave_sum(l1);
-    if (lane == 0) meta[row] = float2{s, l1};
+    if (lane == 0) {
+        meta[row] = float2{s, l1};
+        if (dot_mu) {
+            if (centre_q && !(s > 0.f)) off += fabsf(gamma) * hdr_r->t_max * 1.0000003f;       // q' = 0: no int8 form to carry gamma t_c
+            qoff[row] = off;
+            if (qg) qg[row] = (centre_q && s > 0.f) ? gamma / s : 0.f;
+        }
+    }
 }
 
 // mu for the centred int8 index: the mean of up to MEAN_SAMPLE_ROWS evenly spaced rows, summed in a FIXED order (a block per 64 columns, a
@@ -347,11 +418,28 @@ __global__ __launch_bounds__(256) void rows_mean_kernel(const f16_t* __restrict_
     __syncthreads();
     if (w == 0 && col < D) mu[col] = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (float)S;
 }
+// m^ = mu / |mu| (zero when mu is) and the header (|mu|; the maxima start at zero: quantize_rows_i8_kernel raises them).  One block, fixed order.
+__global__ __launch_bounds__(256) void mean_finish_kernel(const float* __restrict__ mu, int D, float* __restrict__ mhat, I8Header* __restrict__ hdr) {
+    __shared__ float part[256];
+    float a = 0.f;
+    for (int c = threadIdx.x; c < D; c += 256) a = fmaf(mu[c], mu[c], a);
+    part[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    const float nrm = sqrtf(part[0]);
+    const float inv = nrm > 1e-20f ? 1.0f / nrm : 0.f;
+    for (int c = threadIdx.x; c < D; c += 256) mhat[c] = mu[c] * inv;
+    if (threadIdx.x == 0) *hdr = I8Header{nrm, 0.f, 0.f, 0.f};
+}
 
-template <int BM, bool GLDS>
+template <int BM, bool GLDS, bool R1>
 __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* __restrict__ Q8, const float2* __restrict__ qmeta,
-                                                                  const float* __restrict__ qoff, int nq,
+                                                                  const float* __restrict__ qoff, const float* __restrict__ qg, int nq,
                                                                   const int8_t* __restrict__ C8, const float2* __restrict__ cmeta,
+                                                                  const float* __restrict__ ctrow,
                                                                   int64_t n_rows, int D, int tiles_q, int tiles_n,
                                                                   float* __restrict__ gmax, uint32_t* __restrict__ aux, int64_t ldg) {
     using ML = GemmMainloop<i8pair_t, BM, 256, 2, 4, GLDS, GLDS ? 3 : 0>;
@@ -375,7 +463,7 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
     // LDS (two blocks per CU), so the values ride in 36 registers, which that kernel can spare.
     constexpr bool META_LDS = BM >= 128;
     constexpr int MAIN_BYTES = (BM == 256 && GLDS) ? Gemm8Phase<i8pair_t, 2>::STAGE_OFF : ML::SMEM_BYTES;
-    float* const meta = reinterpret_cast<float*>(smem + MAIN_BYTES);          // [512] corpus (s, L1) pairs, then [2 BM] query pairs
+    float* const meta = reinterpret_cast<float*>(smem + MAIN_BYTES);          // the stage of stage_i8_meta
     const int lrow = (lane >> 4) * 4;
     // (the 16 corpus pairs a lane's accumulators belong to are the same for the 16 lanes of a row of the wave: lane t of the row loads ONE
     // pair — row (t>>2)*16 + lrow + (t&3) of the group — and the epilogue fetches the sixteen by ds_bpermute.  Sixteen 8-byte loads per lane
@@ -385,20 +473,22 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
     // k-tile — was built beside it and measured: +0-2 % at D = 768, +6-9 % at D = 384, -2 % for the fp16 rows; not kept.
     // profiles/r04/pass_a_narrow_int8_ab.md)
     float2 cmr = float2{0.f, 0.f}, qmr[META_LDS ? 1 : ML::MI];
-    float qor[META_LDS ? 1 : ML::MI];
+    float qor[META_LDS ? 1 : ML::MI], qgr[(META_LDS || !R1) ? 1 : ML::MI], ctr = 0.f;
     if constexpr (META_LDS) {
-        stage_i8_meta<BM>(cmeta, qmeta, qoff, n0, n_rows, m0, nq, meta, threadIdx.x);
+        stage_i8_meta<BM, R1>(cmeta, ctrow, qmeta, qoff, qg, n0, n_rows, m0, nq, meta, threadIdx.x);
     } else {
         {
             const int t = lane & 15;
             const int64_t n = n0 + wn * GROUP_ROWS + (t >> 2) * 16 + lrow + (t & 3);
             cmr = cmeta[n < n_rows ? n : n_rows - 1];
+            if constexpr (R1) ctr = ctrow[n < n_rows ? n : n_rows - 1];
         }
 #pragma unroll
         for (int i = 0; i < ML::MI; ++i) {
             const int m = m0 + wm * ML::TM + i * 16 + (lane & 15);
             qmr[i] = qmeta[m < nq ? m : nq - 1];
             qor[i] = qoff[m < nq ? m : nq - 1];
+            if constexpr (R1) qgr[i] = qg[m < nq ? m : nq - 1];
         }
     }
     if constexpr (BM == 256 && GLDS) {
@@ -413,21 +503,27 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
     if (wn * GROUP_ROWS >= rows_here) return;
     const int64_t g = (n0 >> 6) + wn;
     if constexpr (META_LDS) {
-        const float* qmeta_l = meta + 512 + (wm * ML::TM + (lane & 15)) * 2;
-        groupmax_epilogue_i8<ML::MI, ML::NI>(acc, MetaFromLds{meta, wn, lrow},
-                                             [&](int i) { return *reinterpret_cast<const float2*>(qmeta_l + i * 32); },
-                                             [&](int i) { return meta[512 + 2 * BM + wm * ML::TM + i * 16 + (lane & 15)]; },
-                                             D, gmax + g * ldg, aux + g * ldg, m0 + wm * ML::TM, nq, lane);
+        const float* qmeta_l = meta + I8_META_Q_OFF + (wm * ML::TM + (lane & 15)) * 2;
+        groupmax_epilogue_i8<ML::MI, ML::NI, R1>(acc, MetaFromLds{meta, wn, lrow},
+                                                 [&](int i) { return *reinterpret_cast<const float2*>(qmeta_l + i * 32); },
+                                                 [&](int i) { return meta[I8_META_Q_OFF + 2 * BM + wm * ML::TM + i * 16 + (lane & 15)]; },
+                                                 TFromLds{meta, wn, lrow},
+                                                 [&](int i) { return meta[I8_META_Q_OFF + 3 * BM + wm * ML::TM + i * 16 + (lane & 15)]; },
+                                                 D, gmax + g * ldg, aux + g * ldg, m0 + wm * ML::TM, nq, lane);
     } else {
-        groupmax_epilogue_i8<ML::MI, ML::NI>(acc, [&](int j, float2 (&c4)[4]) {
+        groupmax_epilogue_i8<ML::MI, ML::NI, R1>(acc, [&](int j, float2 (&c4)[4]) {
 #pragma unroll
-                                                 for (int r = 0; r < 4; ++r) {
-                                                     const int src = (lane & 48) | (j * 4 + r);
-                                                     c4[r] = float2{__shfl(cmr.x, src), __shfl(cmr.y, src)};
-                                                 }
-                                             },
-                                             [&](int i) { return qmr[i]; }, [&](int i) { return qor[i]; }, D, gmax + g * ldg, aux + g * ldg,
-                                             m0 + wm * ML::TM, nq, lane);
+                                                     for (int r = 0; r < 4; ++r) {
+                                                         const int src = (lane & 48) | (j * 4 + r);
+                                                         c4[r] = float2{__shfl(cmr.x, src), __shfl(cmr.y, src)};
+                                                     }
+                                                 },
+                                                 [&](int i) { return qmr[i]; }, [&](int i) { return qor[i]; },
+                                                 [&](int j, float (&t4)[4]) {
+#pragma unroll
+                                                     for (int r = 0; r < 4; ++r) t4[r] = __shfl(ctr, (lane & 48) | (j * 4 + r));
+                                                 },
+                                                 [&](int i) { return qgr[R1 ? i : 0]; }, D, gmax + g * ldg, aux + g * ldg, m0 + wm * ML::TM, nq, lane);
     }
 }
 
@@ -437,7 +533,7 @@ __global__ __launch_bounds__(512) void search_groupmax_i8_kernel(const int8_t* _
 // work (profiles/r03).  Here one block per CU walks its tiles with the operand stream running through the tile boundaries.
 // Tile order: block b belongs to XCD b % 8 and takes corpus tiles = b % 8 (mod 8); inside an XCD the sequence is query-tile fastest, so
 // the (up to four) blocks that read one corpus tile are neighbours in time on ONE L2.
-template <bool I8, bool AUX16 = false>
+template <bool I8, bool AUX16 = false, bool R1 = false>
 struct SearchTilePolicy {
     static constexpr bool REBASE_W = true;
     static constexpr bool PERMUTE_B = false;                     // a group's arg-max row is a position inside the tile: corpus rows stay in order
@@ -445,7 +541,7 @@ struct SearchTilePolicy {
     int64_t n_rows, ldg;
     float* gmax;
     uint32_t* aux;
-    const float2* qmeta; const float2* cmeta; const float* qoff;
+    const float2* qmeta; const float2* cmeta; const float* qoff; const float* qg; const float* ctrow;
     __device__ __forceinline__ bool tile(int o, int& m0, int& n0, int& ko) const {
         const int x = o & 7, L = o >> 3;
         const int tq = L % tiles_q, tn = (L / tiles_q) * 8 + x;
@@ -453,18 +549,20 @@ struct SearchTilePolicy {
         return tn < tiles_n;
     }
     __device__ __forceinline__ void stage_issue(int m0, int n0, char* stage, int wid, int lane) const {
-        if constexpr (I8) stage_i8_meta<256>(cmeta, qmeta, qoff, n0, n_rows, m0, nq, reinterpret_cast<float*>(stage), wid * 64 + lane);
+        if constexpr (I8) stage_i8_meta<256, R1>(cmeta, ctrow, qmeta, qoff, qg, n0, n_rows, m0, nq, reinterpret_cast<float*>(stage), wid * 64 + lane);
     }
     __device__ __forceinline__ void epilogue(const f32x4 (&acc)[4][8], int m0, int n0, int wr, int wc, int lane, const char* stage) const {
         if ((int64_t)n0 + wc * GROUP_ROWS >= n_rows) return;             // the wave's group lies past the shard (wave-uniform)
         const int64_t g = ((int64_t)n0 >> 6) + wc;
         if constexpr (I8) {
             const float* meta = reinterpret_cast<const float*>(stage);
-            const float* qmeta_l = meta + 512 + (wr * 128 + (lane & 15)) * 2;
-            groupmax_epilogue_i8<8, 4>(acc, MetaFromLds{meta, wc, (lane >> 4) * 4},
-                                       [&](int i) { return *reinterpret_cast<const float2*>(qmeta_l + i * 32); },
-                                       [&](int i) { return meta[512 + 2 * 256 + wr * 128 + i * 16 + (lane & 15)]; },
-                                       D, gmax + g * ldg, aux + g * ldg, m0 + wr * 128, nq, lane);
+            const float* qmeta_l = meta + I8_META_Q_OFF + (wr * 128 + (lane & 15)) * 2;
+            groupmax_epilogue_i8<8, 4, R1>(acc, MetaFromLds{meta, wc, (lane >> 4) * 4},
+                                           [&](int i) { return *reinterpret_cast<const float2*>(qmeta_l + i * 32); },
+                                           [&](int i) { return meta[I8_META_Q_OFF + 2 * 256 + wr * 128 + i * 16 + (lane & 15)]; },
+                                           TFromLds{meta, wc, (lane >> 4) * 4},
+                                           [&](int i) { return meta[I8_META_Q_OFF + 3 * 256 + wr * 128 + i * 16 + (lane & 15)]; },
+                                           D, gmax + g * ldg, aux + g * ldg, m0 + wr * 128, nq, lane);
         } else if constexpr (AUX16)
             groupmax_epilogue_f16_aux<8, 4>(acc, gmax + g * ldg, aux + g * ldg, m0 + wr * 128, nq, lane);
         else
@@ -475,15 +573,16 @@ struct SearchTilePolicy {
 #endif
 };
 
-template <typename T, bool I8, bool AUX16>
+template <typename T, bool I8, bool AUX16, bool R1>
 __global__ __launch_bounds__(512) void search_groupmax_persistent_kernel(const T* __restrict__ Q, int nq, const T* __restrict__ C, int64_t n_rows,
                                                                           int Kt /* row length in T elements */, int D, int tiles_q, int tiles_n,
                                                                           const float2* __restrict__ qmeta, const float2* __restrict__ cmeta,
-                                                                          const float* __restrict__ qoff,
+                                                                          const float* __restrict__ qoff, const float* __restrict__ qg,
+                                                                          const float* __restrict__ ctrow,
                                                                           float* __restrict__ gmax, uint32_t* __restrict__ aux, int64_t ldg,
                                                                           unsigned long long* __restrict__ zero_stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (zero_stats && blockIdx.x == 0 && threadIdx.x < 2) zero_stats[threadIdx.x] = 0ull;
-    const SearchTilePolicy<I8, AUX16> pol{tiles_q, tiles_n, nq, D, n_rows, ldg, gmax, aux, qmeta, cmeta, qoff};
+    const SearchTilePolicy<I8, AUX16, R1> pol{tiles_q, tiles_n, nq, D, n_rows, ldg, gmax, aux, qmeta, cmeta, qoff, qg, ctrow};
     gemm8_persistent_body<T>(Q, Kt, C, Kt, nq, (int)n_rows, Kt, pol, smem);
 }

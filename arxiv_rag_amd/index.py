@@ -17,16 +17,19 @@ from . import _lib
 
 class ShardIndex:
     def __init__(self, corpus_f16: torch.Tensor, idx_base: int = 0, prefilter: Optional[str] = None, adaptive: bool = False,
-                 i8_max_queries: Optional[int] = None, max_row_norm: Optional[float] = None):
+                 i8_max_queries: Optional[int] = None, max_row_norm: Optional[float] = None, centre_query: Optional[bool] = None):
         """`prefilter="int8"` (dim % 128 == 0, <= 1024): also keep an int8 representation of the rows (+50 % memory) and run the first
         pass of every search over it — the same exact top-k (`arx_topk_search_i8`), 1.4-1.8x the queries per second on rows that
-        quantise well (the index quantises rows minus the shard's mean, so rows sharing a common component — mean pairwise cosine up to
-        ~0.75 measured — still do; profiles/r04/int8_centred_index.md).  `adaptive=True` (the CLI and `HipCollection` pass it): the index reads the certificate counters after its
+        quantise well (the index quantises rows minus the shard's mean and, `centre_query`, queries minus their component along it, so rows
+        sharing a common component of any size still do; profiles/r04/int8_centred_index.md).  `adaptive=True` (the CLI and `HipCollection` pass it): the index reads the certificate counters after its
         first searches (a 16-byte copy + stream sync each) and switches the pre-filter OFF for good when more than a quarter of a
         batch's queries overflowed their candidate lists — clustered / outlier-heavy rows on which the int8 bound is too slack to
         pay (answers are exact either way; this only picks the faster first pass).
         `i8_max_queries`: THIS index's crossover (query batches above it take the fp16 first pass; None = the library default, 0 = never
         int8) — a per-index policy passed with every call, not a library setting.
+        `centre_query`: the int8 pass also quantises the QUERY minus its component along the shard's mean direction (ARX_TOPK_I8_CENTRE_QUERY: one
+        more instruction per value in pass A's epilogue, same exact answers) — what keeps the pre-filter useful on strongly anisotropic rows
+        (mean pairwise cosine beyond ~0.75).  None (default) = decided from the built index: on when |mean|^2 >= 0.25.
         `max_row_norm`: a bound on the rows' L2 norms the caller vouches for; None (default) = measured on the device
         (`arx_rows_max_norm_f16`, again whenever the tensor was written to) — the exactness certificate's tolerance scales with it, so
         the answers are the exact top-k of the dot products for rows of ANY norm, cosine when they are unit."""
@@ -46,6 +49,7 @@ class ShardIndex:
         self._norm_given = None if max_row_norm is None else float(max_row_norm)
         self._norm, self._norm_version = None, -1
         self._pipe = None                                  # search_many's streams / workspaces
+        self._centre_query_given, self.centre_query, self.i8_mean_norm = centre_query, bool(centre_query), 0.0
         if prefilter == "int8" and self.n_rows > 0:
             self.build_int8()
 
@@ -62,6 +66,11 @@ class ShardIndex:
         _lib.check(self.lib.arx_topk_build_i8(self.corpus.data_ptr(), self.n_rows, self.dim, self._i8.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream), "arx_topk_build_i8")
         self._i8_version = self.corpus._version
+        info = (C.c_float * 3)()
+        _lib.check(self.lib.arx_topk_i8_index_info(self._i8.data_ptr(), self.n_rows, self.dim, info, torch.cuda.current_stream().cuda_stream),
+                   "arx_topk_i8_index_info")
+        self.i8_mean_norm = float(info[0])
+        self.centre_query = (self.i8_mean_norm ** 2 >= 0.25) if self._centre_query_given is None else bool(self._centre_query_given)
 
     def max_row_norm(self) -> float:
         """Upper bound on the L2 norm of the shard's rows (measured on the device unless the caller gave one)."""
@@ -102,7 +111,7 @@ class ShardIndex:
         o = _lib.TopkOptionsC()
         o.i8_max_queries = 0 if self.i8_max_queries is None else (-1 if self.i8_max_queries <= 0 else int(self.i8_max_queries))
         o.max_row_norm = max(self.max_row_norm(), 1.0 + 1.0 / 512.0)      # never below the encoder's unit-row bound
-        o.cu_limit, o.flags = int(cu_limit), int(flags)
+        o.cu_limit, o.flags = int(cu_limit), int(flags) | (_lib.TOPK_I8_CENTRE_QUERY if (self.centre_query and self._use_i8()) else 0)
         o.debug_tau_mult = float(debug.get("tau_mult", 0.0))
         o.debug_drop_best = int(debug.get("drop_best", 0))
         return o

@@ -925,7 +925,20 @@ def main():
                 torch.cuda.synchronize(dev); first_ms = (time.perf_counter() - t0) * 1e3
                 s16_, i16_ = ie.search(qe[:64], 10)
                 i8_adaptive = {"prefilter_switched_off_after_first_batch": bool(ia_e.prefilter_disabled), "first_batch_ms": round(first_ms, 3),
-                               "first_batch_rows_identical_to_fp16_pass": bool(torch.equal(i8_, i16_))}
+                               "first_batch_rows_identical_to_fp16_pass": bool(torch.equal(i8_, i16_)),
+                               "index_mean_norm": round(ia_e.i8_mean_norm, 4), "query_centred_too": bool(ia_e.centre_query)}
+                if not ia_e.prefilter_disabled:              # the int8 first pass ON these rows: per batch, alone and pipelined, against the fp16 pass above
+                    for qb_ in (64, 256):
+                        qs_ = [qe[j:j + qb_] for j in range(0, min(len(qe), 40 * qb_), qb_)]
+                        for _ in range(2): ia_e.search(qs_[0], 10)
+                        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+                        for q_ in qs_: ia_e.search(q_, 10)
+                        torch.cuda.synchronize(dev); t1 = time.perf_counter()
+                        ia_e.search_many(qs_, 10)
+                        torch.cuda.synchronize(dev); t2 = time.perf_counter()
+                        fl_, pr_ = ia_e.certificate_stats()
+                        i8_adaptive[f"Qb={qb_}"] = {"ms_per_batch": round((t1 - t0) / len(qs_) * 1e3, 3), "ms_per_batch_pipelined": round((t2 - t1) / len(qs_) * 1e3, 3),
+                                                    "queries_overflowed_in_last_batch": int(fl_), "candidate_groups_per_query": round(pr_ / qb_, 1)}
                 del ia_e
             chk = None
             if rank == 0:

@@ -165,6 +165,9 @@ int32_t arx_topk_search(const void* corpus, int64_t n_rows, const void* queries,
 int64_t arx_topk_i8_index_bytes(int64_t n_rows, int32_t dim);
 int64_t arx_topk_workspace_bytes_i8(int64_t n_rows, int32_t n_queries, int32_t dim, int32_t k);
 int32_t arx_topk_build_i8(const void* corpus, int64_t n_rows, int32_t dim, void* index_i8, void* stream);
+/* {|mu|, max |t_c|, max sum |c'_i m^_i|} of a built index -> host_out[3] (synchronises the stream): |mu| is what a caller needs to decide on
+ * ARX_TOPK_I8_CENTRE_QUERY. */
+int32_t arx_topk_i8_index_info(const void* index_i8, int64_t n_rows, int32_t dim, float* host_out, void* stream);
 int32_t arx_topk_search_i8(const void* corpus, const void* index_i8, int64_t n_rows, const void* queries, int32_t n_queries,
                            int32_t dim, int32_t k, float* out_scores, int64_t* out_ids, int64_t idx_base,
                            void* ws, int64_t ws_bytes, void* stream);
@@ -175,6 +178,9 @@ int32_t arx_topk_search_i8(const void* corpus, const void* index_i8, int64_t n_r
 #define ARX_TOPK_NO_SINGLE_ROW_TAIL 8 /* flags: take the select + rescore kernel pair (all 64 rows of each selected group) where the library would take the
                                       single-kernel tail that rescoring only the arg-max 4-row block (fp16 pass: batches of <= 256 queries, k <= 10, shards
                                       of <= 1 M rows) or the arg-max row (int8 pipeline's first step) of each selected group — A/B measurements, tests */
+#define ARX_TOPK_I8_CENTRE_QUERY 16 /* flags (int8 pass): quantise the QUERY minus its component along the index's mean direction as well, the rank-one term
+                                      that leaves added exactly in pass A (one more instruction per value of its epilogue).  For indexes whose rows share a large
+                                      common component (arx_topk_i8_index_info: |mu|^2 = the mean pairwise cosine of unit rows); same exact answers either way */
 #define ARX_TOPK_SCAN_ONLY     2   /* flags: run only pass A (the scan of the shard: every CU, HBM-bound) and leave its result in the workspace */
 #define ARX_TOPK_TAIL_ONLY     4   /* flags: run only what follows pass A (select, exact rescoring, certificate) on a workspace a SCAN_ONLY call
                                       with the same arguments filled; the caller orders the two calls (possibly on two streams with different

@@ -85,7 +85,7 @@ while time.time() - t0 < secs:
     for pre in (None, "int8"):
         if pre == "int8" and (d % 128 != 0 or n >= (1 << 32)):
             continue
-        idx = ShardIndex(c16, idx_base=base, prefilter=pre)
+        idx = ShardIndex(c16, idx_base=base, prefilter=pre, centre_query=[None, None, True, False][ri(0, 3)])      # (int8: the query centred as well, or not, or the index's own choice)
         s, i = idx.search(q16, k)
         what = dict(n=n, d=d, nq=nq, k=k, pre=pre, base=base, flavour=flavour, scale=round(scale, 3), seed=seed, case=cases)
         validate(c16, q16, s, i, k, base, tol, what)
