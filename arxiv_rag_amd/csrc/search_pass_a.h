@@ -317,9 +317,9 @@ __global__ __launch_bounds__(512) void search_groupmax_kernel(const f16_t* __res
 // in pass A's epilogue (one fma with gamma / s_q and the row's t_c, which the index stores).  Roundings: q'_i = fma(-gamma, m^_i, q_i) is one
 // rounding of the exact value (inside the 0.0001 s_q allowance, as for the rows); t_c as computed differs from m^.(c - mu) by at most
 // 2.2e-6 sum |c'_i m^_i| <= 2.2e-6 E (E: the largest such sum over the shard, kept in the index header), gamma / s_q and the epilogue's fma
-// add 2.4e-7 |gamma| T (T: the largest |t_c|): both go into the query's offset.  A query that IS the common direction (q' = 0, s_q = 0) gets
+// add 2.4e-7 |gamma| T (T: the largest |t_c|): both go into the query's offset (with the first of the epilogue's two roundings, see the kernel's end).  A query that IS the common direction (q' = 0, s_q = 0) gets
 // |gamma| T in its offset instead of the rank-one term.
-struct I8Header { float mu_norm, t_max, e_max, pad; };
+struct I8Header { float mu_norm, t_max, e_max, c_amax; };      // |mu|; max |t_c|; max sum |c'_i m^_i|; max |c'_i| — over the shard's rows
 __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __restrict__ X, int64_t n_rows, int D, int8_t* __restrict__ X8,
                                                                 float2* __restrict__ meta, unsigned long long* __restrict__ zero_stats,
                                                                 const float* __restrict__ sub_mu, const float* __restrict__ dot_mu,
@@ -351,10 +351,12 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __re
             t = fmaf(v[e], m, t); mag = fmaf(fabsf(v[e]), fabsf(m), mag);
         }
         t = wave_sum(t); mag = wave_sum(mag);
+        const float amax_row = wave_max(amax);
         if (lane == 0) {
             trow[row] = t;
             atomicMax(reinterpret_cast<unsigned int*>(&hdr_w->t_max), __float_as_uint(fabsf(t)));      // non-negative floats order as their bit patterns
             atomicMax(reinterpret_cast<unsigned int*>(&hdr_w->e_max), __float_as_uint(mag));
+            atomicMax(reinterpret_cast<unsigned int*>(&hdr_w->c_amax), __float_as_uint(amax_row));
         }
     }
     if (dot_mu) {                                  // (a query row: its offset q . mu, rounded up)
@@ -393,6 +395,9 @@ __global__ __launch_bounds__(256) void quantize_rows_i8_kernel(const f16_t* __re
         meta[row] = float2{s, l1};
         if (dot_mu) {
             if (centre_q && !(s > 0.f)) off += fabsf(gamma) * hdr_r->t_max * 1.0000003f;       // q' = 0: no int8 form to carry gamma t_c
+            // the epilogue's value is now the sum of TWO roundings (u1 = the int8 bound, then + (gamma / s_q) t_c): where the two nearly cancel, the
+            // first one's error, 2^-24 |u1|, is not small relative to the result.  |u1| s_q <= s_q s_c (127.5 L1(q8) + 64 D + 2), s_c <= c_amax / 127
+            if (centre_q && s > 0.f) off += 1.2e-7f * s * (hdr_r->c_amax * (1.0f / 127.0f)) * (127.5f * l1 + 64.0f * (float)D + 2.0f);
             qoff[row] = off;
             if (qg) qg[row] = (centre_q && s > 0.f) ? gamma / s : 0.f;
         }
