@@ -975,6 +975,42 @@ def test_int8_index_is_centred_rows_with_a_large_common_component_keep_the_prefi
         _assert_same_topk_up_to_ties(C_, qs, i8.search(qs, 10), ShardIndex(C_).search(qs, 10))
 
 
+def test_int8_bounds_are_upper_bounds_of_every_group(hip):
+    """The int8 pass promises, per (query, 64-row group), an UPPER BOUND of the true fp16 score of every row of the group.  Checked directly — not through the final answers, which the certificate would repair — by
+    running the scan alone (ARX_TOPK_SCAN_ONLY) and reading the bound array out of the workspace (layout: 256 bytes of counters, then
+    [groups][round_up(queries, 64)] floats): every kernel
+    form (per-tile 64 / 128 / 256-query tiles, the persistent one), rows with and without a large common component, the query centred or not,
+    ragged shard, rows of norm 0.2 ... 3."""
+    from arxiv_rag_amd.index import ShardIndex
+    from arxiv_rag_amd import _lib
+    F = torch.nn.functional
+    d, n = 768, 64 * 700 + 29
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    u = F.normalize(torch.randn(d, generator=g, device="cuda"), dim=0)
+    for amp in (0.0, 0.6, 2.0):
+        base = F.normalize(amp * u[None, :] + 0.3 * F.normalize(torch.randn((n, d), generator=g, device="cuda"), dim=1), dim=1)
+        nrm = torch.empty(n, device="cuda").uniform_(0.2, 3.0, generator=g) if amp == 0.6 else torch.ones(n, device="cuda")
+        C_ = (base * nrm[:, None]).half()
+        Qall = F.normalize(amp * u[None, :] + 0.3 * F.normalize(torch.randn((300, d), generator=g, device="cuda"), dim=1), dim=1).half()
+        n_groups = (n + 63) // 64
+        for cq in (False, True):
+            idx = ShardIndex(C_, prefilter="int8", centre_query=cq)
+            for nq in (1, 64, 128, 300):
+                Q_ = Qall[:nq]
+                ws = idx.alloc_workspace(nq, 10)
+                idx.search(Q_, 10, ws=ws, flags=_lib.TOPK_SCAN_ONLY)
+                torch.cuda.synchronize()
+                ldg = (nq + 63) // 64 * 64
+                ub = ws[256:256 + n_groups * ldg * 4].view(torch.float32).view(n_groups, ldg)[:, :nq]
+                true = (Q_.float() @ C_.float().T).T                                    # [n, nq]
+                true = torch.cat([true, torch.full((n_groups * 64 - n, nq), float("-inf"), device="cuda")]).view(n_groups, 64, nq)
+                tmax = true.max(dim=1).values                                             # [groups, nq]
+                slack = (ub - tmax)
+                assert slack.min().item() >= -1e-7, (amp, cq, nq, slack.min().item())
+                # not vacuous: the bound is tight to a few hundredths on average (and far tighter on centred anisotropic rows)
+                assert slack.mean().item() < 0.2, (amp, cq, nq, slack.mean().item())
+
+
 def test_int8_index_follows_writes_to_the_corpus(hip):
     """the int8 copy is a snapshot; rows written afterwards (ShardSink.put, the encoder) must not be searched through
     stale int8 values.  The index notices the tensor's version counter and rebuilds."""
