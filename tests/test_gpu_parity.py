@@ -1009,6 +1009,21 @@ def test_int8_bounds_are_upper_bounds_of_every_group(hip):
                 assert slack.min().item() >= -1e-7, (amp, cq, nq, slack.min().item())
                 # not vacuous: the bound is tight to a few hundredths on average (and far tighter on centred anisotropic rows)
                 assert slack.mean().item() < 0.2, (amp, cq, nq, slack.mean().item())
+                # the aux word of the same (query, group): high half = an upper bound (bf16 image, rounded up) of every row of the group EXCEPT the one
+                # at the position in its low 6 bits — what lets the candidate step read one row of a group.  (Layout, csrc/search.hip topk_layout:
+                # counters, bounds, two selection arrays of nsplit x ldg x 36 words, then the aux words in the bounds' shape; 256-byte aligned.)
+                r256 = lambda b: (b + 255) // 256 * 256
+                n_super = (n_groups + 15) // 16
+                nsplit = max(1, min(256, (n_super + 7) // 8))
+                off = 256 + r256(n_groups * ldg * 4) + 2 * r256(nsplit * ldg * 36 * 4)
+                aux = ws[off:off + n_groups * ldg * 4].view(torch.int32).view(n_groups, ldg)[:, :nq]
+                ub2 = (aux & -65536).view(torch.float32)
+                arg = (aux & 63).long()                                                   # [groups, nq]
+                others = true.clone()
+                others.scatter_(1, arg[:, None, :], float("-inf"))
+                o2 = others.max(dim=1).values
+                fin = torch.isfinite(o2)
+                assert (ub2[fin] - o2[fin]).min().item() >= -1e-7, (amp, cq, nq, (ub2[fin] - o2[fin]).min().item())
 
 
 def test_int8_index_follows_writes_to_the_corpus(hip):
